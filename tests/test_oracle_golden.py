@@ -1,0 +1,282 @@
+"""Pins oracle/snws_oracle.py against fixtures produced by the reference itself
+(tests/golden/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import snws_oracle as O
+import patterns
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= atol * scale + rtol * scale, (err, scale)
+
+
+# ---------------------------------------------------------------- Conv2dws
+@pytest.mark.parametrize("ci", range(4))
+def test_conv2dws_golden(ci):
+    g = load("g1_conv2dws")
+    pre = "c%d_" % ci
+    Oc, I, k, s, p, d, has_b = [int(v) for v in g[pre + "cfg"]]
+    w = torch.from_numpy(g[pre + "w"])
+    x = torch.from_numpy(g[pre + "x"])
+    b = torch.from_numpy(g[pre + "b"]) if has_b else None
+    dy = torch.from_numpy(g[pre + "dy"])
+    close(O.ws_standardize(w), g[pre + "what"])
+    close(O.conv2dws_fwd(x, w, b, s, p, d), g[pre + "y"])
+    dx, dw, db = O.conv2dws_bwd(x, w, dy, bool(has_b), s, p, d)
+    close(dx, g[pre + "dx"])
+    close(dw, g[pre + "dw"], rtol=2e-4)
+    if has_b:
+        close(db, g[pre + "db"])
+
+
+def test_ws_bwd_matches_autograd_f64():
+    w = torch.from_numpy(patterns.fill((6, 5, 3, 3), 3, 0.8)).double().requires_grad_(True)
+    g = torch.from_numpy(patterns.fill((6, 5, 3, 3), 9, 1.0)).double()
+    O.ws_standardize(w).backward(g)
+    close(O.ws_standardize_bwd(w.detach(), g), w.grad, rtol=1e-11, atol=1e-12)
+
+
+# ---------------------------------------------------------------- SwitchNorm
+def _sn_cases():
+    g = load("g2_switchnorm")
+    return sorted({k[:-4] for k in g.files if k.endswith("_cfg")})
+
+
+def _sn_state(g, pre):
+    N, C, H, W, mov, ubn, lg = [int(v) for v in g[pre + "cfg"]]
+    st = O.SNState(C, using_movavg=mov, using_bn=ubn, last_gamma=lg)
+    st.gamma = torch.from_numpy(g[pre + "gamma"]).reshape(-1).clone()
+    st.beta = torch.from_numpy(g[pre + "beta"]).reshape(-1).clone()
+    st.mean_weight = torch.from_numpy(g[pre + "mw"]).clone()
+    st.var_weight = torch.from_numpy(g[pre + "vw"]).clone()
+    return st, ubn
+
+
+@pytest.mark.parametrize("pre", _sn_cases())
+def test_switchnorm_golden(pre):
+    g = load("g2_switchnorm")
+    pre = pre + "_"
+    st, ubn = _sn_state(g, pre)
+    x = torch.from_numpy(g[pre + "x"])
+    dy = torch.from_numpy(g[pre + "dy"])
+    y, ctx = O.switchnorm_fwd(x, st, training=True)
+    close(y, g[pre + "y"])
+    dx, dga, dbe, dmw, dvw = O.switchnorm_bwd(dy, st, ctx)
+    close(dx, g[pre + "dx"], rtol=2e-4)
+    close(dga, g[pre + "dgamma"].reshape(-1), rtol=2e-4)
+    close(dbe, g[pre + "dbeta"].reshape(-1), rtol=2e-4)
+    close(dmw, g[pre + "dmw"], rtol=5e-4, atol=1e-4)
+    close(dvw, g[pre + "dvw"], rtol=5e-4, atol=1e-4)
+    if ubn:
+        close(st.running_mean, g[pre + "rm1"].reshape(-1))
+        close(st.running_var, g[pre + "rv1"].reshape(-1))
+        for j in range(3):
+            O.switchnorm_fwd(x * (1.0 + 0.5 * (j + 1)) - 0.3 * j, st, training=True)
+        close(st.running_mean, g[pre + "rm4"].reshape(-1))
+        close(st.running_var, g[pre + "rv4"].reshape(-1))
+    y_eval, _ = O.switchnorm_fwd(x, st, training=False)
+    close(y_eval, g[pre + "y_eval"])
+
+
+def test_switchnorm_bwd_matches_autograd_f64_with_relu():
+    torch.manual_seed(0)
+    N, C, H, W = 3, 5, 4, 6
+    st = O.SNState(C, dtype=torch.float64)
+    st.gamma = (torch.rand(C, dtype=torch.float64) + 0.5).requires_grad_(True)
+    st.beta = torch.randn(C, dtype=torch.float64).requires_grad_(True)
+    st.mean_weight = torch.randn(3, dtype=torch.float64).requires_grad_(True)
+    st.var_weight = torch.randn(3, dtype=torch.float64).requires_grad_(True)
+    x = torch.randn(N, C, H, W, dtype=torch.float64).requires_grad_(True)
+    dy = torch.randn(N, C, H, W, dtype=torch.float64)
+    y, ctx = O.switchnorm_fwd(x, st, training=True, relu=True)
+    y.backward(dy)
+    with torch.no_grad():
+        dx, dga, dbe, dmw, dvw = O.switchnorm_bwd(dy, st, ctx)
+    for a, b in ((dx, x.grad), (dga, st.gamma.grad), (dbe, st.beta.grad), (dmw, st.mean_weight.grad),
+                 (dvw, st.var_weight.grad)):
+        close(a, b, rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+def test_switchnorm_sharded_equals_global_batch(shards):
+    """Data-parallel identity: shard-local SwitchNorm with all-reduced BN sums == the reference run on
+    the whole batch (fixture s3 has N=4)."""
+    g = load("g2_switchnorm")
+    pre = "s3_bn_mov_"
+    x = torch.from_numpy(g[pre + "x"]).double()
+    dy = torch.from_numpy(g[pre + "dy"]).double()
+    N = x.shape[0]
+    per = N // shards
+    sts = []
+    for r in range(shards):
+        st, _ = _sn_state(g, pre)
+        for a in ("gamma", "beta", "mean_weight", "var_weight", "running_mean", "running_var"):
+            setattr(st, a, getattr(st, a).double())
+        sts.append(st)
+    xs = [x[r * per:(r + 1) * per] for r in range(shards)]
+    # forward: emulate the all-reduce by summing every shard's pack
+    packs = []
+    for r in range(shards):
+        O.switchnorm_fwd(xs[r], sts[r], True, allreduce=lambda p: (packs.append(p.clone()), p)[1])
+    total = torch.stack(packs).sum(0)
+    for st, _ in [(_sn_state(g, pre))]:
+        pass
+    ys, ctxs = [], []
+    sts = []
+    for r in range(shards):
+        st, _ = _sn_state(g, pre)
+        for a in ("gamma", "beta", "mean_weight", "var_weight", "running_mean", "running_var"):
+            setattr(st, a, getattr(st, a).double())
+        sts.append(st)
+        y, ctx = O.switchnorm_fwd(xs[r], st, True, allreduce=lambda p: total)
+        ys.append(y)
+        ctxs.append(ctx)
+    close(torch.cat(ys), g[pre + "y"], rtol=1e-5)
+    close(sts[0].running_mean, g[pre + "rm1"].reshape(-1), rtol=1e-5)
+    close(sts[1].running_var, g[pre + "rv1"].reshape(-1), rtol=1e-5)
+    # backward: first collect packs, then rerun with the total
+    bpacks = []
+    for r in range(shards):
+        O.switchnorm_bwd(dy[r * per:(r + 1) * per], sts[r], ctxs[r], allreduce=lambda p: (bpacks.append(p.clone()), p)[1])
+    btotal = torch.stack(bpacks).sum(0)
+    outs = [O.switchnorm_bwd(dy[r * per:(r + 1) * per], sts[r], ctxs[r], allreduce=lambda p: btotal) for r in range(shards)]
+    close(torch.cat([o[0] for o in outs]), g[pre + "dx"], rtol=2e-4)
+    close(sum(o[1] for o in outs), g[pre + "dgamma"].reshape(-1), rtol=2e-4)
+    close(sum(o[3] for o in outs), g[pre + "dmw"], rtol=5e-4, atol=1e-4)
+    close(sum(o[4] for o in outs), g[pre + "dvw"], rtol=5e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- resampling vs stock torch
+@pytest.mark.parametrize("k,hw", [(2, (8, 8)), (4, (8, 16)), (8, (16, 8)), (2, (5, 7)), (4, (9, 6))])
+def test_maxpool_ceil(k, hw):
+    x = torch.from_numpy(patterns.fill((2, 3) + hw, k, 1.0)).float()
+    ref = torch.nn.functional.max_pool2d(x, k, k, ceil_mode=True)
+    assert torch.equal(O.maxpool_ceil(x, k), ref)
+
+
+@pytest.mark.parametrize("s", [2, 4, 8, 16])
+def test_upsample_bilinear(s):
+    x = torch.from_numpy(patterns.fill((2, 3, 4, 5), s, 1.0)).float()
+    ref = torch.nn.functional.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False)
+    close(O.upsample_bilinear(x, s), ref, rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------- whole models
+def _state_from_pattern(arch, nf=4):
+    st = O.make_state(arch, 14, nf, 10)
+
+    class _M:  # adapter so patterns.det_init can walk "named_parameters" in the reference's order
+        def named_parameters(self_inner):
+            return [(k, v) for k, v in st.items() if not O.is_buffer(k)]
+    patterns.det_init(_M())
+    return st
+
+
+@pytest.mark.parametrize("arch,tag", [("unet", "g4_unet"), ("unet3p", "g4_unet3p")])
+def test_model_golden(arch, tag):
+    g = load(tag)
+    st = _state_from_pattern(arch)
+    assert list(st.keys()) == [str(k) for k in g["state_keys"]]
+    assert [",".join(map(str, v.shape)) for v in st.values()] == [str(s) for s in g["state_shapes"]]
+    img, lab = patterns.synth_batch(2, 14, 64, 101)
+    logits, loss, grads = O.model_step(arch, st, img, lab, training=True)
+    close(logits, g["logits"], rtol=1e-3, atol=1e-4)
+    assert abs(loss - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    for name in g["param_names"]:
+        name = str(name)
+        ref = g["grad:" + name]
+        got = grads[name].numpy()
+        denom = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(got - ref).max() <= 2e-3 * denom + 1e-6, name
+    for k in st:
+        if O.is_buffer(k):
+            close(st[k], g["buf:" + k], rtol=1e-4)
+    logits_eval, _, _ = O.model_step(arch, st, img, lab, training=False)
+    close(logits_eval, g["logits_eval"], rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------- evaluator
+@pytest.mark.parametrize("case,C", [("a", 10), ("b", 10), ("e", 3)])
+def test_evaluator_golden(case, C):
+    g = load("g6_evaluator")
+    gt, pr = g[case + "_gt"], g[case + "_pred"]
+    cm = O.confusion_matrix(gt, pr, C)
+    if case == "a":
+        cm = cm + O.confusion_matrix(gt[::-1].copy(), pr, C)
+    assert np.array_equal(cm.astype(np.float64), g[case + "_cm"])
+    pa, pac, miou, fw = O.evaluator_metrics(cm)
+    for got, key in ((pa, "_pa"), (pac, "_pac"), (miou, "_miou"), (fw, "_fwiou")):
+        assert np.array_equal(np.asarray(got, np.float64).view(np.uint64), g[case + key].view(np.uint64)), key
+
+
+def test_evaluator_all_ignored_and_full_disk():
+    g = load("g6_evaluator")
+    cm = O.confusion_matrix(np.full((1, 8, 8), 255.0, np.float32), np.zeros((1, 8, 8), np.int64), 10)
+    assert np.array_equal(cm, g["c_cm"])
+    pa, pac, miou, fw = O.evaluator_metrics(cm)
+    assert np.isnan(pa) and np.isnan(g["c_pa"]) and np.isnan(miou) and np.isnan(g["c_miou"])
+    assert fw == g["c_fwiou"] == 0.0
+    rng = np.random.default_rng(int(g["d_seed"]))
+    gt = rng.integers(0, 10, size=(1, 2748, 2748)).astype(np.float32)
+    pr = rng.integers(0, 10, size=(1, 2748, 2748)).astype(np.int64)
+    cm = O.confusion_matrix(gt, pr, 10)
+    assert np.array_equal(cm.astype(np.float64), g["d_cm"])
+    pa, pac, miou, fw = O.evaluator_metrics(cm)
+    assert pa == g["d_pa"] and miou == g["d_miou"] and fw == g["d_fwiou"]
+
+
+def test_evaluator_out_of_range_prediction_raises():
+    with pytest.raises(ValueError):
+        O.confusion_matrix(np.array([9.0]), np.array([10]), 10)
+
+
+# ---------------------------------------------------------------- misc
+def test_tiles_lr_ce_golden():
+    g = load("g78_misc")
+    for i in range(int(g["n_tiles_cases"])):
+        args = [int(v) for v in g["tiles%d_args" % i]]
+        assert np.array_equal(np.array(O.gen_tiles_offs(*args), np.int64), g["tiles%d" % i])
+    for (i, ep), lr in zip(g["lr_pts"], g["lr_vals"]):
+        assert O.poly_lr(0.002, int(ep) * 746 + int(i), 200 * 746) == lr
+    logit = torch.from_numpy(g["ce_logit"]).requires_grad_(True)
+    loss = O.ce_loss_batch_avg(logit, torch.from_numpy(g["ce_target"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["ce_loss"])) < 1e-6
+    close(logit.grad, g["ce_dlogit"], rtol=1e-5, atol=1e-7)
+
+
+def test_loss_curve_golden_prefix():
+    """First 12 steps of the 200-step AdamW/poly curve (the full curve is the GPU test's target)."""
+    g = load("g5_loss_curve")
+    st = _state_from_pattern("unet3p")
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if not O.is_buffer(k)}
+    full = dict(st)
+    full.update(params)
+    opt = torch.optim.AdamW(list(params.values()), lr=2e-3, weight_decay=5e-4)
+    batches = [patterns.synth_batch_learnable(4, 14, 64, 200 + j) for j in range(4)]
+    for i in range(12):
+        for gi in opt.param_groups:
+            gi["lr"] = O.poly_lr(2e-3, i, 200)
+        assert abs(opt.param_groups[0]["lr"] - float(g["lrs"][i])) < 1e-12
+        opt.zero_grad()
+        net = O.OracleNet(full)
+        img, lab = batches[i % 4]
+        loss = O.ce_loss_batch_avg(net.unet3p(img), lab)
+        loss.backward()
+        opt.step()
+        assert abs(float(loss) - float(g["losses"][i])) <= 2e-3 * float(g["losses"][i]), i
