@@ -1,0 +1,178 @@
+/* libsnws - C ABI of the MI355X (gfx950) normalized-conv hot path.
+ *
+ * Drop-in boundary for the weight-standardized Conv2d -> SwitchNorm2d -> ReLU stack, its resampling
+ * skips, and the Evaluator confusion matrix of the reference (paths below are relative to the
+ * reference repository root).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative snws_status; snws_last_error() gives the text
+ *    (thread-local).  No exception crosses this boundary.
+ *  - All data pointers are DEVICE pointers valid on `stream` (a hipStream_t passed as void*; NULL = the
+ *    null stream).  Kernels are enqueued asynchronously; nothing here synchronises or allocates.
+ *  - Activations are NHWC ("channels last"): element (n,y,x,c) lives at ((n*H+y)*W+x)*ld + c where the
+ *    pixel stride `ld` (in elements) may exceed C so that a tensor can be a channel slice of a wider
+ *    concat buffer.  The logical shape seen by the reference API (N,C,H,W) is unchanged.
+ *  - dtype: SNWS_F32 or SNWS_BF16 for activations; statistics, coefficients and master weights are f32.
+ */
+#ifndef SNWS_H
+#define SNWS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { SNWS_OK = 0, SNWS_ERR_INVALID = -1, SNWS_ERR_UNSUPPORTED = -2, SNWS_ERR_HIP = -3 } snws_status;
+typedef enum { SNWS_F32 = 0, SNWS_BF16 = 1, SNWS_F64 = 2, SNWS_I64 = 3, SNWS_I32 = 4, SNWS_U8 = 5 } snws_dtype;
+
+int snws_version(void);
+const char* snws_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Evaluator confusion matrix - replaces Evaluator._generate_matrix, utils/metrics.py:40-45
+ * (and, for the *_argmax form, the logits D2H + np.argmax of train.py:294-296).
+ *
+ * counts: int64[num_class*num_class + 2], ACCUMULATED into (caller zeroes it at Evaluator.reset()):
+ *   counts[num_class*gt + pred] += 1 for every pixel whose label passes (gt >= 0) & (gt < num_class),
+ *   with the label truncated toward zero like astype('int'); rows = ground truth, cols = prediction.
+ *   counts[C*C]   += pixels whose index C*gt+pred fell at or beyond C*C   (np.bincount would grow -> reshape raises)
+ *   counts[C*C+1] += pixels whose index was negative                      (np.bincount raises)
+ * gt_dtype: SNWS_F32 | SNWS_F64 | SNWS_I64 | SNWS_I32 | SNWS_U8; pred_dtype: SNWS_I64 | SNWS_I32 | SNWS_U8.
+ * num_class <= 64. */
+int snws_confusion_hist(const void* gt, int gt_dtype, const void* pred, int pred_dtype, int64_t n_pixels,
+                        int num_class, int64_t* counts, void* stream);
+
+/* Same, with pred = argmax over the channel axis of NHWC logits (first maximum wins, a NaN counts as
+ * the maximum, as numpy.argmax): logits (n_pixels, ld) of logit_dtype SNWS_F32 | SNWS_BF16. */
+int snws_confusion_hist_argmax(const void* gt, int gt_dtype, const void* logits, int logit_dtype, int64_t ld,
+                               int64_t n_pixels, int num_class, int64_t* counts, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight standardisation - replaces Conv2dws.forward lines modeling/weightstd.py:13-17 and their autograd.
+ *
+ * w: f32 (O, I, kh, kw) master weight (PyTorch layout).  n = I*kh*kw must be >= 2.
+ * what_oihw (nullable): f32 (O, I, kh, kw) standardized weight.
+ * what_ohwi (nullable): f32 (O, kh, kw, I) standardized weight for the direct (generic) conv kernels.
+ * pack_fwd / pack_dgrad (nullable): bf16 MFMA operand images for snws_conv_mfma_*; sizes from
+ *   snws_conv_pack_bytes().  pack_dgrad holds the spatially flipped, in/out-transposed filter. */
+int snws_ws_fwd(const float* w, int O, int I, int kh, int kw, float* what_oihw, float* what_ohwi, void* pack_fwd,
+                void* pack_dgrad, void* stream);
+
+/* dw (O,I,kh,kw) f32 = gradient w.r.t. the master weight given g = dL/d(what) stored as (O, kh, kw, ldg)
+ * with ldg >= I (the wgrad kernels' output layout). */
+int snws_ws_bwd(const float* w, const float* g_ohwi, int64_t ldg, float* dw, int O, int I, int kh, int kw,
+                void* stream);
+
+/* Bytes of one MFMA operand image for a conv with these channel counts / kernel size. */
+int64_t snws_conv_pack_bytes(int c_in, int c_out, int kh, int kw);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution - replaces F.conv2d at modeling/weightstd.py:18 and its autograd (dgrad, wgrad, bias grad).
+ *
+ * Generic direct kernels: any stride / padding / dilation / groups, dtype f32 or bf16, f32 accumulate.
+ *   x (N,H,W,ldx) -> y (N,OH,OW,ldy);  weight f32 (O, kh, kw, I/groups);  bias f32 (O) or NULL. */
+typedef struct {
+  int N, H, W, C_in, C_out, kh, kw, stride, pad, dil, groups;
+  int64_t ldx, ldy; /* pixel strides (elements) of the input-side and output-side tensors */
+} snws_conv_desc;
+
+int snws_conv_out_size(int in, int k, int stride, int pad, int dil);
+int snws_conv_direct_fwd(const snws_conv_desc* d, int dtype, const void* x, const float* w_ohwi, const float* bias,
+                         void* y, void* stream);
+/* dx (N,H,W,ldx) = dgrad; every element of the C_in channels is written. */
+int snws_conv_direct_dgrad(const snws_conv_desc* d, int dtype, const void* dy, const float* w_ohwi, void* dx,
+                           void* stream);
+/* dw_ohwi f32 (O, kh, kw, I/groups) overwritten; dbias f32 (O) overwritten when non-NULL. */
+int snws_conv_direct_wgrad(const snws_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_ohwi,
+                           float* dbias, void* stream);
+
+/* MFMA implicit-GEMM kernels: bf16 NHWC, f32 accumulate, kernel 3x3 (pad 1) or 1x1 (pad 0), stride 1,
+ * dilation 1, groups 1, C_in a multiple of 16, C_out a multiple of 8.  Returns SNWS_ERR_UNSUPPORTED otherwise.
+ *   fwd:   y = conv(x, pack_fwd) + bias.  When stat_part != NULL it also emits per-tile partial moments
+ *          of the ROUNDED output for SwitchNorm: stat_part[((n*T + t)*C_out + c)*2 + {0,1}] = sum and sum of
+ *          squares of (y - bias[c]) over tile t's valid pixels, T = snws_conv_mfma_tiles(H, W).
+ *   dgrad: the same kernel run on dy with pack_dgrad (desc as for fwd; reads C_out channels, writes C_in).
+ *   wgrad: dw_ohwi f32 (O, kh, kw, C_in) and dbias (O) are ACCUMULATED into with float atomics (zero them first). */
+int snws_conv_mfma_tiles(int H, int W);
+int snws_conv_mfma_fwd(const snws_conv_desc* d, const void* x, const void* pack_fwd, const float* bias, void* y,
+                       float* stat_part, void* stream);
+int snws_conv_mfma_dgrad(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx, void* stream);
+int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SwitchNorm - replaces SwitchNorm2d.forward, modeling/snorm.py:41-81, fused with the ReLU that follows it
+ * in ConvSnRelu (modeling/UNet3p_SNws.py:29-33), and its autograd.
+ *
+ * One invocation works on x (N, HW, C) with pixel stride ldx.  Small f32 side buffers:
+ *   part   (N, T, C, 2)  per-tile partial sums of (x - shift) and (x - shift)^2
+ *   shift  (N, C) or (C) the per-channel offset the partial sums were taken around
+ *   ctx    snws_sn_ctx_floats(N, C) floats: [mean_in NC][var_in NC][mean NC][rstd NC][scale NC][ln 2N][bn 2C]
+ *   pack   (2C+1): [sum_n mean_in, sum_n (var_in+mean_in^2), N_local] - the data-parallel all-reduce payload
+ *          (the replacement for the _ChildMessage/_MasterMessage exchange of
+ *          modeling/sync_batchnorm/batchnorm.py:24-25,80-101); the caller all-reduces it between
+ *          snws_sn_mix_a and snws_sn_mix_b when training on several GPUs.
+ */
+int64_t snws_sn_ctx_floats(int N, int C);
+int snws_sn_stats_tiles(int N, int64_t HW, int C);
+
+/* Pass 1 (stand-alone form): partial moments of x.  part has T = snws_sn_stats_tiles(N,HW,C) tiles per image;
+ * shift (N,C) is written with x's first pixel of each image. */
+int snws_sn_stats(const void* x, int dtype, int N, int64_t HW, int C, int64_t ldx, float* part, float* shift,
+                  void* stream);
+/* Partial moments -> ctx.mean_in / ctx.var_in (unbiased, /(HW-1); snorm.py:45-46).  shift_per_image: 1 if shift is
+ * (N,C), 0 if it is (C) (the conv epilogue's bias). */
+int snws_sn_finalize(const float* part, int T, const float* shift, int shift_per_image, int N, int64_t HW, int C,
+                     float* ctx, void* stream);
+/* LN moments (snorm.py:48-50) into ctx.ln and the local BN sums into pack. */
+int snws_sn_mix_a(float* ctx, float* pack, int N, int C, void* stream);
+/* Mix the three branches (snorm.py:52-77), update the running buffers (training && using_bn; snorm.py:56-63),
+ * write ctx.mean / ctx.rstd / ctx.scale.  mean_weight/var_weight have 3 (using_bn) or 2 entries.
+ * pack is read after the caller's all-reduce: pack[2C] is the GLOBAL batch size. */
+int snws_sn_mix_b(float* ctx, const float* pack, const float* gamma, const float* mean_weight,
+                  const float* var_weight, float* running_mean, float* running_var, int N, int C, float eps,
+                  float momentum, int training, int using_movavg, int using_bn, void* stream);
+/* y = act((x - ctx.mean) * ctx.scale + beta [+ residual]), act = ReLU if relu else identity (snorm.py:79-81).
+ * residual (nullable) has pixel stride ldr and y's dtype. */
+int snws_sn_apply(const void* x, int64_t ldx, void* y, int64_t ldy, const void* residual, int64_t ldr, int dtype,
+                  const float* ctx, const float* beta, int N, int64_t HW, int C, int relu, void* stream);
+
+/* Backward.  ctxb: snws_sn_ctxb_floats(N,C) floats of scratch/coefficients. */
+int64_t snws_sn_ctxb_floats(int N, int C);
+/* Pass 1: per-tile partial sums of dy' and dy'*xhat (dy' = dy masked by the ReLU), part (N,T,C,2).
+ * When y_for_mask != NULL the mask is (y_for_mask > 0) (needed with a residual add); otherwise it is recomputed
+ * from x. */
+int snws_sn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask, int64_t ldy,
+                       int dtype, const float* ctx, const float* gamma, const float* beta, int N, int64_t HW, int C,
+                       int relu, float* part, void* stream);
+/* Partials -> dm, dv per (n,c); per-image and per-channel sums; dgamma/dbeta (C) overwritten;
+ * packb (2C) = [sum_n dm, sum_n dv] is the backward all-reduce payload. */
+int snws_sn_bwd_mix_a(const float* part, int T, const float* ctx, const float* gamma, float* ctxb, float* packb,
+                      float* dgamma, float* dbeta, int N, int C, void* stream);
+/* After the caller's all-reduce of packb: coefficients A,B,K of dx = A*dy' + B*x + K into ctxb, and the
+ * gradients of mean_weight / var_weight (overwritten, 3 or 2 entries).  n_global = global batch size. */
+int snws_sn_bwd_mix_b(const float* ctx, float* ctxb, const float* packb, const float* mean_weight,
+                      const float* var_weight, const float* running_mean, const float* running_var,
+                      float* dmean_weight, float* dvar_weight, int N, int64_t HW, int C, float n_global,
+                      int training, int using_bn, void* stream);
+/* Pass 2: dx = A*dy' + B*x + K. */
+int snws_sn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask, int64_t ldy,
+                      void* dx, int64_t lddx, int dtype, const float* ctx, const float* ctxb, const float* beta,
+                      int N, int64_t HW, int C, int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Full-scale skip resampling - replaces nn.MaxPool2d(k,k,ceil_mode=True) / nn.Upsample(scale, bilinear,
+ * align_corners=False) / torch.cat at modeling/UNet3p_SNws.py:49-55,127-156 and their autograd.
+ *
+ * mode 0: copy, 1: max-pool factor k (window clipped at the border, out = ceil(in/k)), 2: bilinear up x k.
+ * src (N,H,W,lds) C channels -> dst (N,OH,OW,ldd) written at the destination's channel slice (dst pointer already
+ * offset).  bwd accumulates (+=) into dsrc, which the caller zeroes or reuses across consumers. */
+int snws_resample_fwd(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int N, int H, int W, int C,
+                      int mode, int k, void* stream);
+int snws_resample_bwd(const void* ddst, int64_t ldd, const void* src, int64_t lds, void* dsrc, int64_t ldds,
+                      int dtype, int N, int H, int W, int C, int mode, int k, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,550 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on the gfx950 bf16 matrix cores (replaces F.conv2d at
+// modeling/weightstd.py:18 of the reference and its autograd for the stride-1 "same" convolutions of the
+// UNet3+ stack).  NHWC bf16 activations, f32 accumulation, v_mfma_f32_32x32x16_bf16.
+//
+// Forward / dgrad (one kernel; dgrad = forward over dy with the flipped, transposed filter image):
+//   workgroup = 4 waves = a 16x32 pixel patch of one image x 64 output channels; wave w owns rows 4w..4w+3.
+//   GEMM orientation: D[out channel][pixel] = sum_k A[out channel][k] * B[k][pixel], k = (tap, in channel).
+//   The contraction walks KC input channels at a time: the (16+2)x(32+2) input halo patch and the filter slab of
+//   that chunk are copied global->LDS with 16-byte LDS-DMA loads (out-of-image pixels read a zero page), then
+//   every tap reads its shifted B fragments from the SAME halo patch.  Pixels are 16-byte-chunk XOR-swizzled so
+//   the 16 lanes of a ds_read_b128 group hit 16 distinct bank slots; the swizzle is applied to the per-lane
+//   SOURCE address because LDS-DMA writes lane-linearly.  Two workgroups per CU (76.8 KB LDS each) overlap one
+//   block's staging with the other's MFMAs.
+//   Epilogue: accumulators (+bias) -> bf16 -> LDS -> 128-byte-per-pixel coalesced stores, plus optional
+//   per-tile sum / sum-of-squares of the ROUNDED outputs per channel, which SwitchNorm consumes instead of
+//   re-reading the tensor.
+//
+// Wgrad: D[out channel][in channel] = sum over pixels; both operands are needed pixel-major per lane, so the
+//   NHWC tiles are read from LDS with the transposing ds_read_b64_tr_b16.  A workgroup owns a 64x64 (out,in)
+//   filter tile for all taps (144 accumulator registers per lane), sweeps a slice of the pixel tiles, and adds
+//   its result to the f32 gradient with float atomics (128-byte segments per wave-instruction).
+#include "common.h"
+#include "pack.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(8))) short short8v;
+
+constexpr int ZERO_PAGE_BYTES = 8192;
+__device__ __attribute__((aligned(256))) unsigned int snws_zero_page[ZERO_PAGE_BYTES / 4];  // never written: all zero
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware block id: blocks that are dealt to the same XCD (bid % 8) get consecutive logical ids, so tiles that
+// share an input patch or a filter slab also share an L2.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+struct FwdArgs {
+  const bf16_t* x;
+  const bf16_t* pack;
+  const float* bias;
+  bf16_t* y;
+  float* stat;
+  int N, H, W, Cout;
+  int64_t ldx, ldy;
+  int tilesX, tilesY, coTiles, nchunks;
+};
+
+constexpr int FWD_TH = 16, FWD_TW = 32;
+constexpr int OUT_STRIDE = 144;                       // bytes per pixel row of the epilogue tile (128 + 16 pad)
+constexpr int OUT_BYTES = FWD_TH * FWD_TW * OUT_STRIDE;  // 73,728
+constexpr int STAT_BYTES = 4 * 64 * 2 * 4;            // per-wave channel partials
+
+template <int KC, int TAPS>
+struct FwdGeom {
+  static constexpr int PADK = TAPS == 9 ? 1 : 0;
+  static constexpr int HWd = FWD_TW + 2 * PADK, HHt = FWD_TH + 2 * PADK, NPIX = HWd * HHt;
+  static constexpr int PIXB = KC * 2, VPP = KC / 8, PPI = 64 / VPP;
+  static constexpr int NI = (NPIX + PPI - 1) / PPI, IN_BYTES = NI * 1024;
+  static constexpr int KS = KC / 16, W_BYTES = TAPS * KS * 2048, NIW = W_BYTES / 1024;
+  static constexpr int JIN = (NI + 3) / 4, JW = (NIW + 3) / 4;
+  static constexpr int MAIN_BYTES = IN_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = (MAIN_BYTES > OUT_BYTES + STAT_BYTES) ? MAIN_BYTES : OUT_BYTES + STAT_BYTES;
+};
+
+// 16-byte-chunk XOR swizzle of a halo pixel, a function of its COLUMN only: a ds_read_b128 lane group reads 16
+// consecutive columns of one row, and the row then enters the address as a compile-time immediate.
+template <int VPP>
+__device__ __forceinline__ int col_swz(int px) {
+  return VPP == 4 ? ((px >> 2) & 3) : ((px >> 3) & 1);
+}
+
+template <int KC, int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(FwdArgs a) {
+  using G = FwdGeom<KC, TAPS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* in_lds = smem;
+  unsigned char* w_lds = smem + G::IN_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = L % a.coTiles;
+  unsigned pt_ = L / a.coTiles;
+  const int tx = pt_ % a.tilesX; pt_ /= a.tilesX;
+  const int ty = pt_ % a.tilesY;
+  const int n = pt_ / a.tilesY;
+  const int y0 = ty * FWD_TH, x0 = tx * FWD_TW;
+
+  // per-lane source of every input LDS-DMA this wave issues, as a byte offset from the image base
+  // (constant across chunks except the channel offset); ~0u marks a pixel outside the image
+  const unsigned char* img = reinterpret_cast<const unsigned char*>(a.x + (int64_t)n * a.H * a.W * a.ldx);
+  unsigned src[G::JIN];
+#pragma unroll
+  for (int j = 0; j < G::JIN; ++j) {
+    const int i = wave + 4 * j;
+    const int pix = i * G::PPI + lane / G::VPP;
+    const int py = pix / G::HWd, px = pix - py * G::HWd;
+    const int gy = y0 - G::PADK + py, gx = x0 - G::PADK + px;
+    const bool ok = (i < G::NI) && (pix < G::NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int chunk = (lane % G::VPP) ^ col_swz<G::VPP>(px);
+    src[j] = ok ? (unsigned)((((int64_t)gy * a.W + gx) * a.ldx + chunk * 8) * 2) : ~0u;
+  }
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c2][p][r] = 0.f;
+
+  const int r = lane & 31, h = lane >> 5;
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.pack) + (int64_t)ct * a.nchunks * G::W_BYTES;
+  // LDS read bases: one per (kw, k-step) for the pixel operand (tile rows and kh are immediates), one for the filter
+  constexpr int KWN = TAPS == 9 ? 3 : 1;
+  const unsigned char* bbase[KWN][G::KS];
+#pragma unroll
+  for (int kw = 0; kw < KWN; ++kw)
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+      bbase[kw][ks] = in_lds + (wave * 4 * G::HWd + r + kw) * G::PIXB + (((ks * 2 + h) ^ col_swz<G::VPP>(r + kw)) * 16);
+  const unsigned char* abase = w_lds + h * 1024 + r * 16;
+
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    // ---- stage this chunk: halo patch + filter slab
+#pragma unroll
+    for (int j = 0; j < G::JIN; ++j) {
+      const int i = wave + 4 * j;
+      if (i < G::NI) {
+        const unsigned char* p = src[j] == ~0u ? reinterpret_cast<const unsigned char*>(snws_zero_page)
+                                               : img + src[j] + ch * (KC * 2);
+        glds16(p, in_lds + i * 1024);
+      }
+    }
+    const unsigned char* wslab = wbase + (int64_t)ch * G::W_BYTES + lane * 16;
+#pragma unroll
+    for (int j = 0; j < G::JW; ++j) {
+      const int i = wave + 4 * j;
+      if (i < G::NIW) glds16(wslab + i * 1024, w_lds + i * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- MFMAs: every tap reads its shifted fragments from the same halo patch
+#pragma unroll
+    for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < (TAPS == 9 ? 3 : 1); ++kw) {
+        const int tap = kh * 3 + kw;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+          bf16x8 af[2], bfr[4];
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+            af[c2] = *reinterpret_cast<const bf16x8*>(abase + (tap * G::KS + ks) * 2048 + c2 * 512);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            bfr[p] = *reinterpret_cast<const bf16x8*>(bbase[kw][ks] + (p + kh) * (G::HWd * G::PIXB));
+          }
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              acc[c2][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c2], bfr[p], acc[c2][p], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators (+bias) -> bf16 tile in LDS.  D[row = out channel][col = pixel]:
+  //      lane holds pixel r of its 32-pixel row and out channels (reg&3) + 8*(reg>>2) + 4*h.
+  const int co0 = ct * 64;
+  unsigned char* out_lds = smem;
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cl = c2 * 32 + 8 * g + 4 * h;  // first of 4 consecutive channels
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = (co0 + cl + e < a.Cout) ? a.bias[co0 + cl + e] : 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int q = (wave * 4 + p) * 32 + r;
+        uint2 v;
+        v.x = pack_bf16x2(acc[c2][p][4 * g + 0] + b4[0], acc[c2][p][4 * g + 1] + b4[1]);
+        v.y = pack_bf16x2(acc[c2][p][4 * g + 2] + b4[2], acc[c2][p][4 * g + 3] + b4[3]);
+        *reinterpret_cast<uint2*>(out_lds + q * OUT_STRIDE + cl * 2) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- coalesced stores (8 lanes x 16 B = one pixel's 64 channels) + per-channel partial moments
+  const int j8 = tid & 7, q0 = tid >> 3;
+  const int cbase = co0 + j8 * 8;
+  const bool cok = cbase < a.Cout;
+  float sh[8], S[8], Q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sh[e] = (a.stat && a.bias && cok) ? a.bias[cbase + e] : 0.f;
+    S[e] = Q[e] = 0.f;
+  }
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int q = q0 + 32 * i;
+    const int gy = y0 + (q >> 5), gx = x0 + (q & 31);
+    if (cok && gy < a.H && gx < a.W) {
+      const uint4 v = *reinterpret_cast<const uint4*>(out_lds + q * OUT_STRIDE + j8 * 16);
+      *reinterpret_cast<uint4*>(a.y + (((int64_t)n * a.H + gy) * a.W + gx) * a.ldy + cbase) = v;
+      if (a.stat) {
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f0 = __uint_as_float(u[e] << 16) - sh[2 * e];
+          const float f1 = __uint_as_float(u[e] & 0xffff0000u) - sh[2 * e + 1];
+          S[2 * e] += f0; Q[2 * e] += f0 * f0;
+          S[2 * e + 1] += f1; Q[2 * e + 1] += f1 * f1;
+        }
+      }
+    }
+  }
+  if (a.stat) {
+    float* st_lds = reinterpret_cast<float*>(smem + OUT_BYTES);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        S[e] += __shfl_xor(S[e], o, 64);
+        Q[e] += __shfl_xor(Q[e], o, 64);
+      }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        st_lds[(wave * 64 + lane * 8 + e) * 2] = S[e];
+        st_lds[(wave * 64 + lane * 8 + e) * 2 + 1] = Q[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 64 && co0 + tid < a.Cout) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s += st_lds[(w * 64 + tid) * 2];
+        q += st_lds[(w * 64 + tid) * 2 + 1];
+      }
+      const int64_t tile = (int64_t)ty * a.tilesX + tx;
+      const int64_t T = (int64_t)a.tilesX * a.tilesY;
+      float* o = a.stat + (((int64_t)n * T + tile) * a.Cout + co0 + tid) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- wgrad
+struct WgradArgs {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* dw;
+  float* dbias;
+  int N, H, W, Cin, Cout;   // Cin: channels of x that take part (multiple of 16); dw rows have Cin entries
+  int64_t ldx, lddy;
+  int tilesX, tilesY, coTiles, ciTiles, tilesPerSplit;
+};
+
+constexpr int WG_TH = 8, WG_TW = 32;
+
+template <int CIC, int TAPS>
+struct WgGeom {
+  static constexpr int PADK = TAPS == 9 ? 1 : 0;
+  static constexpr int HWd = WG_TW + 2 * PADK, HHt = WG_TH + 2 * PADK, NPIX = HWd * HHt;
+  static constexpr int XPIXB = CIC * 2, XVPP = CIC / 8, XPPI = 64 / XVPP;
+  static constexpr int XNI = (NPIX + XPPI - 1) / XPPI, X_BYTES = XNI * 1024 + 64;  // +64: harmless over-read of the last pixel (CIC=16)
+  static constexpr int DY_NI = WG_TH * WG_TW / 8, DY_BYTES = DY_NI * 1024;         // [256 px][64 ch] bf16
+  static constexpr int JX = (XNI + 3) / 4, JD = DY_NI / 4;
+  static constexpr int LDS_BYTES = DY_BYTES + ((X_BYTES + 15) / 16) * 16 + 4 * 64 * 4;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p_lo, const unsigned char* p_hi) {
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p_lo);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p_hi);
+  short8v v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int CIC, int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+  using G = WgGeom<CIC, TAPS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* dy_lds = smem;
+  unsigned char* x_lds = smem + G::DY_BYTES;
+  float* b_lds = reinterpret_cast<float*>(smem + G::DY_BYTES + ((G::X_BYTES + 15) / 16) * 16);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int npairs = a.coTiles * a.ciTiles;
+  const int pair = blockIdx.x % npairs, split = blockIdx.x / npairs;
+  const int cot = pair % a.coTiles, cit = pair / a.coTiles;
+  const int ntiles = a.N * a.tilesY * a.tilesX;
+  const int t_begin = split * a.tilesPerSplit;
+  const int t_end = t_begin + a.tilesPerSplit < ntiles ? t_begin + a.tilesPerSplit : ntiles;
+
+  // wave roles: out-channel half (32 of the tile's 64) x {in-channel half (CIC=64) | pixel-row half (CIC=16)}
+  const int co_half = wave & 1, other = wave >> 1;
+  const int ci_half = CIC == 64 ? other : 0;
+  constexpr int NKS = CIC == 64 ? 16 : 8;
+  const int ks_begin = CIC == 64 ? 0 : other * 8;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  // transposing-read lane geometry: 16-lane group g: rows (channels) rb = 16*(g&1).., k half kb = 8*(g>>1);
+  // lane 4q+p of the group addresses pixel (kb + q), channels 4p..4p+3 of the group's 16.
+  const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
+  const int rb = (grp & 1) * 16, kb = (grp >> 1) * 8;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    int tt = t;
+    const int tx = tt % a.tilesX; tt /= a.tilesX;
+    const int ty = tt % a.tilesY;
+    const int n = tt / a.tilesY;
+    const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+    // ---- stage dy tile [256 px][64 ch] (8 lanes per pixel) and the x halo tile
+#pragma unroll
+    for (int j = 0; j < G::JD; ++j) {
+      const int i = wave + 4 * j;
+      const int pix = i * 8 + (lane >> 3);
+      const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+      const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
+      const bool ok = gy < a.H && gx < a.W;
+      const void* s = ok ? (const void*)(a.dy + (((int64_t)n * a.H + gy) * a.W + gx) * a.lddy + cot * 64 + chunk * 8)
+                         : (const void*)snws_zero_page;
+      glds16(s, dy_lds + i * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < G::JX; ++j) {
+      const int i = wave + 4 * j;
+      if (i < G::XNI) {
+        const int pix = i * G::XPPI + lane / G::XVPP;
+        const int py = pix / G::HWd, px = pix - py * G::HWd;
+        const int gy = y0 - G::PADK + py, gx = x0 - G::PADK + px;
+        const int cl = lane % G::XVPP;
+        const int chunk = CIC == 64 ? (cl ^ (((pix >> 1) & 1) << 2)) : cl;
+        const bool ok = pix < G::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const void* s = ok ? (const void*)(a.x + (((int64_t)n * a.H + gy) * a.W + gx) * a.ldx + cit * CIC + chunk * 8)
+                           : (const void*)snws_zero_page;
+        glds16(s, x_lds + i * 1024);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (a.dbias && cit == 0) {  // bias gradient: column sums of the dy tile (block-uniform branch)
+      const int co = tid & 63, part = tid >> 6;
+      const int c8 = co >> 3, e = co & 7;
+      float s = 0.f;
+      for (int i = 0; i < 64; ++i) {
+        const int pix = part * 64 + i;
+        const int chunk = c8 ^ (((pix >> 1) & 1) << 2);
+        s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(dy_lds + pix * 128 + chunk * 16 + e * 2));
+      }
+      bsum += s;
+    }
+
+#pragma unroll 2
+    for (int kk = 0; kk < NKS; ++kk) {
+      const int ks = ks_begin + kk;
+      const int ty_ = ks >> 1, cb = (ks & 1) * 16 + kb + gq;  // tile row, first of this lane's two pixel columns
+      // A: dy, rows = out channels co_half*32 + rb + 4*gp.., k = pixels
+      const int ach = co_half * 32 + rb + 4 * gp;             // channel within the 64-wide tile
+      const int p_lo = ty_ * 32 + cb, p_hi = p_lo + 4;
+      const unsigned char* a_lo = dy_lds + p_lo * 128 + (((ach >> 3) ^ (((p_lo >> 1) & 1) << 2)) * 16) + (ach & 7) * 2;
+      const unsigned char* a_hi = dy_lds + p_hi * 128 + (((ach >> 3) ^ (((p_hi >> 1) & 1) << 2)) * 16) + (ach & 7) * 2;
+      const bf16x8 af = tr_frag(a_lo, a_hi);
+      const int bch = ci_half * 32 + rb + 4 * gp;
+#pragma unroll
+      for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < (TAPS == 9 ? 3 : 1); ++kw) {
+          const int h_lo = (ty_ + kh) * G::HWd + cb + kw, h_hi = h_lo + 4;
+          const unsigned char *b_lo, *b_hi;
+          if (CIC == 64) {
+            b_lo = x_lds + h_lo * 128 + (((bch >> 3) ^ (((h_lo >> 1) & 1) << 2)) * 16) + (bch & 7) * 2;
+            b_hi = x_lds + h_hi * 128 + (((bch >> 3) ^ (((h_hi >> 1) & 1) << 2)) * 16) + (bch & 7) * 2;
+          } else {
+            b_lo = x_lds + h_lo * G::XPIXB + bch * 2;
+            b_hi = x_lds + h_hi * G::XPIXB + bch * 2;
+          }
+          const bf16x8 bfr = tr_frag(b_lo, b_hi);
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[kh * 3 + kw], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
+  const int ci = cit * CIC + ci_half * 32 + (lane & 31);
+  const bool ci_ok = (CIC == 64 || (lane & 31) < 16) && ci < a.Cin;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 64 + co_half * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (ci_ok && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * TAPS + t) * a.Cin + ci, acc[t][r]);
+    }
+  }
+  if (a.dbias && cit == 0) {
+    b_lds[tid] = bsum;
+    __syncthreads();
+    if (tid < 64 && cot * 64 + tid < a.Cout)
+      atomicAdd(a.dbias + cot * 64 + tid, b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host
+int check_mfma_desc(const snws_conv_desc* d, const char* fn) {
+  SNWS_CHECK_ARG(d, "%s: desc is NULL", fn);
+  SNWS_CHECK_ARG(d->N >= 1 && d->H >= 1 && d->W >= 1 && d->C_in >= 1 && d->C_out >= 1, "%s: non-positive size", fn);
+  const bool k3 = d->kh == 3 && d->kw == 3 && d->pad == 1, k1 = d->kh == 1 && d->kw == 1 && d->pad == 0;
+  if (!(k3 || k1) || d->stride != 1 || d->dil != 1 || d->groups != 1)
+    SNWS_UNSUPPORTED("%s: only 3x3/pad1 or 1x1/pad0, stride 1, dilation 1, groups 1 (got k=%dx%d s=%d p=%d d=%d g=%d)", fn,
+                     d->kh, d->kw, d->stride, d->pad, d->dil, d->groups);
+  if (d->C_in % 16 || d->C_out % 8) SNWS_UNSUPPORTED("%s: C_in %d must be a multiple of 16 and C_out %d of 8", fn, d->C_in, d->C_out);
+  if (d->ldx % 8 || d->ldy % 8) SNWS_UNSUPPORTED("%s: pixel strides must be multiples of 8 elements", fn);
+  if (d->C_in > (ZERO_PAGE_BYTES - 64) / 2 || d->C_out > (ZERO_PAGE_BYTES - 64) / 2)
+    SNWS_UNSUPPORTED("%s: more than %d channels", fn, (ZERO_PAGE_BYTES - 64) / 2);
+  SNWS_CHECK_ARG(d->ldx >= d->C_in && d->ldy >= d->C_out, "%s: pixel stride smaller than channel count", fn);
+  if ((int64_t)d->H * d->W * d->ldx * 2 >= 0xFFFFFFFFll || (int64_t)d->H * d->W * d->ldy * 2 >= 0xFFFFFFFFll)
+    SNWS_UNSUPPORTED("%s: one image exceeds 4 GiB", fn);
+  return SNWS_OK;
+}
+
+template <int KC, int TAPS>
+int launch_fwd(const FwdArgs& a, unsigned grid, hipStream_t st) {
+  using G = FwdGeom<KC, TAPS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<KC, TAPS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  conv_fwd_kernel<KC, TAPS><<<grid, 256, G::LDS_BYTES, st>>>(a);
+  SNWS_LAUNCH_CHECK("snws_conv_mfma_fwd");
+  return SNWS_OK;
+}
+
+// runs y(C_out_run channels) = conv(x(C_in_run channels), pack)
+int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_run, int taps, const void* x, int64_t ldx,
+                 const void* pack, const float* bias, void* y, int64_t ldy, float* stat, hipStream_t st) {
+  SNWS_CHECK_ARG(x && pack && y, "%s: NULL pointer", fn);
+  SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)pack & 15) == 0,
+                 "%s: pointers must be 16-byte aligned", fn);
+  const PackGeom g = pack_geom(c_in_run, c_out_run, taps);
+  FwdArgs a;
+  a.x = (const bf16_t*)x; a.pack = (const bf16_t*)pack; a.bias = bias; a.y = (bf16_t*)y; a.stat = stat;
+  a.N = N; a.H = H; a.W = W; a.Cout = c_out_run; a.ldx = ldx; a.ldy = ldy;
+  a.tilesX = cdiv(W, FWD_TW); a.tilesY = cdiv(H, FWD_TH); a.coTiles = g.c_out_p / 64; a.nchunks = g.nchunks;
+  const int64_t nblk = (int64_t)N * a.tilesX * a.tilesY * a.coTiles;
+  SNWS_CHECK_ARG(nblk < (1ll << 31), "%s: grid too large", fn);
+  if (g.KC == 32) return taps == 9 ? launch_fwd<32, 9>(a, (unsigned)nblk, st) : launch_fwd<32, 1>(a, (unsigned)nblk, st);
+  return taps == 9 ? launch_fwd<16, 9>(a, (unsigned)nblk, st) : launch_fwd<16, 1>(a, (unsigned)nblk, st);
+}
+
+template <int CIC, int TAPS>
+int launch_wgrad(const WgradArgs& a, unsigned grid, hipStream_t st) {
+  using G = WgGeom<CIC, TAPS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<CIC, TAPS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  conv_wgrad_kernel<CIC, TAPS><<<grid, 256, G::LDS_BYTES, st>>>(a);
+  SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
+  return SNWS_OK;
+}
+
+}  // namespace
+
+extern "C" int snws_conv_mfma_tiles(int H, int W) { return cdiv(H, FWD_TH) * cdiv(W, FWD_TW); }
+
+extern "C" int snws_conv_mfma_fwd(const snws_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
+                                  void* y, float* stat_part, void* stream) {
+  if (int rc = check_mfma_desc(d, "snws_conv_mfma_fwd")) return rc;
+  return run_fwd_like("snws_conv_mfma_fwd", d->N, d->H, d->W, d->C_in, d->C_out, d->kh * d->kw, x, d->ldx, pack_fwd, bias,
+                      y, d->ldy, stat_part, (hipStream_t)stream);
+}
+
+extern "C" int snws_conv_mfma_dgrad(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx,
+                                    void* stream) {
+  if (int rc = check_mfma_desc(d, "snws_conv_mfma_dgrad")) return rc;
+  if (d->C_out % 16 || d->C_in % 8) SNWS_UNSUPPORTED("snws_conv_mfma_dgrad: C_out %d must be a multiple of 16 and C_in %d of 8", d->C_out, d->C_in);
+  return run_fwd_like("snws_conv_mfma_dgrad", d->N, d->H, d->W, d->C_out, d->C_in, d->kh * d->kw, dy, d->ldy, pack_dgrad,
+                      nullptr, dx, d->ldx, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
+                                    void* stream) {
+  if (int rc = check_mfma_desc(d, "snws_conv_mfma_wgrad")) return rc;
+  SNWS_CHECK_ARG(x && dy && dw_ohwi, "snws_conv_mfma_wgrad: NULL pointer");
+  SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "snws_conv_mfma_wgrad: pointers must be 16-byte aligned");
+  const bool c64 = d->C_in % 64 == 0, c16 = d->C_in == 16;
+  if (!(c64 || c16) || d->C_out % 64)
+    SNWS_UNSUPPORTED("snws_conv_mfma_wgrad: C_in %d must be 16 or a multiple of 64 and C_out %d a multiple of 64", d->C_in, d->C_out);
+  WgradArgs a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw_ohwi; a.dbias = dbias;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->C_in; a.Cout = d->C_out; a.ldx = d->ldx; a.lddy = d->ldy;
+  a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
+  a.coTiles = d->C_out / 64; a.ciTiles = c64 ? d->C_in / 64 : 1;
+  const int ntiles = d->N * a.tilesX * a.tilesY, npairs = a.coTiles * a.ciTiles;
+  int splits = cdiv(2048, npairs);
+  if (splits > ntiles) splits = ntiles;
+  a.tilesPerSplit = cdiv(ntiles, splits);
+  splits = cdiv(ntiles, a.tilesPerSplit);
+  const unsigned grid = (unsigned)(npairs * splits);
+  const int taps = d->kh * d->kw;
+  hipStream_t st = (hipStream_t)stream;
+  if (c64) return taps == 9 ? launch_wgrad<64, 9>(a, grid, st) : launch_wgrad<64, 1>(a, grid, st);
+  return taps == 9 ? launch_wgrad<16, 9>(a, grid, st) : launch_wgrad<16, 1>(a, grid, st);
+}

@@ -1,0 +1,841 @@
+// SwitchNorm forward/backward for NHWC activations (replaces modeling/snorm.py:41-81 of the reference and its
+// autograd, fused with the ReLU that follows it in ConvSnRelu).
+//
+// HBM-bound streaming kernels.  The two big passes per direction read 16 B per lane with a fixed channel group
+// per thread, so the per-(n,c) coefficients live in registers and consecutive lanes touch consecutive bytes:
+//   forward : [stats (or the conv epilogue's partial moments)] -> finalize -> mix_a -> (all-reduce) -> mix_b -> apply
+//   backward: bwd_reduce -> bwd_mix_a -> (all-reduce) -> bwd_mix_b -> bwd_apply
+// Moments are accumulated as sums of (x - shift) and (x - shift)^2 per tile in f32 and combined across tiles in
+// f64, in a fixed order, so results are bit-reproducible run to run.
+#include "common.h"
+
+namespace {
+
+constexpr int SN_THREADS = 256;
+
+struct SnMap {  // how 256 threads cover (pixel rows) x (channel groups)
+  int CG, cgb, PR, active;
+};
+inline SnMap sn_map(int C, int V) {
+  SnMap m;
+  m.CG = C / V;
+  m.cgb = m.CG < SN_THREADS ? m.CG : SN_THREADS;
+  m.PR = SN_THREADS / m.cgb;
+  m.active = m.cgb * m.PR;
+  return m;
+}
+
+inline int sn_tiles(int N, int64_t HW, int C) {
+  int64_t per_img = HW * (int64_t)C;
+  int64_t T = cdiv64(per_img, 32768);
+  int64_t cap = 4096 / (N > 0 ? N : 1);
+  if (cap < 1) cap = 1;
+  if (T > cap) T = cap;
+  if (T < 1) T = 1;
+  int64_t PT = cdiv64(HW, T);
+  return (int)cdiv64(HW, PT);
+}
+
+// ctx layout (floats)
+struct CtxOff {
+  int64_t mean_in, var_in, mean, rstd, scale, ln, bn, total;
+};
+__host__ __device__ inline CtxOff ctx_off(int N, int C) {
+  CtxOff o;
+  int64_t NC = (int64_t)N * C;
+  o.mean_in = 0; o.var_in = NC; o.mean = 2 * NC; o.rstd = 3 * NC; o.scale = 4 * NC;
+  o.ln = 5 * NC; o.bn = 5 * NC + 2 * N; o.total = 5 * NC + 2 * N + 2 * C;
+  return o;
+}
+struct CtxbOff {
+  int64_t P, Q, dm, dv, B, K, lnb, total;
+};
+__host__ __device__ inline CtxbOff ctxb_off(int N, int C) {
+  CtxbOff o;
+  int64_t NC = (int64_t)N * C;
+  o.P = 0; o.Q = NC; o.dm = 2 * NC; o.dv = 3 * NC; o.B = 4 * NC; o.K = 5 * NC; o.lnb = 6 * NC; o.total = 6 * NC + 2 * N;
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------- pass 1: moments
+template <typename T, int V>
+__global__ __launch_bounds__(SN_THREADS) void sn_stats_kernel(const T* __restrict__ x, int64_t HW, int C, int64_t ldx,
+                                                              int PT, int Tn, SnMap m, float* __restrict__ part,
+                                                              float* __restrict__ shift_out) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][PR][cgb*V]
+  const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int64_t p0 = (int64_t)t * PT;
+  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  const T* xn = x + (int64_t)n * HW * ldx;
+  const int cgl = tid % m.cgb, prow = tid / m.cgb;
+  const int row = m.cgb * V;
+  for (int cg0 = 0; cg0 < m.CG; cg0 += m.cgb) {
+    const int cg = cg0 + cgl;
+    const bool valid = tid < m.active && cg < m.CG;
+    float S[V], Q[V], sh[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) S[v] = Q[v] = sh[v] = 0.f;
+    if (valid) {
+      Vec<T, V>::load(xn + (int64_t)cg * V, sh);  // first pixel of the image: the offset of the shifted sums
+      if (t == 0 && prow == 0) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) shift_out[(int64_t)n * C + cg * V + v] = sh[v];
+      }
+      int64_t p = p0 + prow;
+      for (; p + 3 * m.PR < p1; p += 4 * m.PR) {
+        float a[V], b[V], c[V], d[V];
+        Vec<T, V>::load(xn + p * ldx + (int64_t)cg * V, a);
+        Vec<T, V>::load(xn + (p + m.PR) * ldx + (int64_t)cg * V, b);
+        Vec<T, V>::load(xn + (p + 2 * m.PR) * ldx + (int64_t)cg * V, c);
+        Vec<T, V>::load(xn + (p + 3 * m.PR) * ldx + (int64_t)cg * V, d);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float e0 = a[v] - sh[v], e1 = b[v] - sh[v], e2 = c[v] - sh[v], e3 = d[v] - sh[v];
+          S[v] += (e0 + e1) + (e2 + e3);
+          Q[v] += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+        }
+      }
+      for (; p < p1; p += m.PR) {
+        float a[V];
+        Vec<T, V>::load(xn + p * ldx + (int64_t)cg * V, a);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float e = a[v] - sh[v];
+          S[v] += e;
+          Q[v] += e * e;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < m.active) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        red[prow * row + cgl * V + v] = S[v];
+        red[m.PR * row + prow * row + cgl * V + v] = Q[v];
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < row; j += SN_THREADS) {
+      const int ch = cg0 * V + j;
+      if (ch < C) {
+        float s = 0.f, q = 0.f;
+        for (int r = 0; r < m.PR; ++r) {
+          s += red[r * row + j];
+          q += red[m.PR * row + r * row + j];
+        }
+        float* o = part + (((int64_t)n * Tn + t) * C + ch) * 2;
+        o[0] = s;
+        o[1] = q;
+      }
+    }
+  }
+}
+
+// partial moments -> mean_in, var_in (unbiased)
+__global__ __launch_bounds__(512) void sn_finalize_kernel(const float* __restrict__ part, int T,
+                                                          const float* __restrict__ shift, int shift_per_image, int N,
+                                                          int64_t HW, int C, float* __restrict__ ctx) {
+  __shared__ double red[2][8][64];
+  const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
+  double S = 0, Q = 0;
+  if (c < C) {
+    for (int t = tl; t < T; t += 8) {
+      const float* p = part + (((int64_t)n * T + t) * C + c) * 2;
+      S += (double)p[0];
+      Q += (double)p[1];
+    }
+  }
+  red[0][tl][cl] = S;
+  red[1][tl][cl] = Q;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    S = 0; Q = 0;
+    for (int i = 0; i < 8; ++i) { S += red[0][i][cl]; Q += red[1][i][cl]; }
+    const CtxOff o = ctx_off(N, C);
+    const double sh = (double)shift[shift_per_image ? (int64_t)n * C + c : c];
+    const double m = S / (double)HW;
+    const double var = (Q - S * m) / (double)(HW - 1);
+    ctx[o.mean_in + (int64_t)n * C + c] = (float)(sh + m);
+    ctx[o.var_in + (int64_t)n * C + c] = (float)var;
+  }
+}
+
+// LN moments per image, local BN sums per channel
+__global__ __launch_bounds__(256) void sn_mix_a_kernel(float* __restrict__ ctx, float* __restrict__ pack, int N, int C) {
+  __shared__ double scratch[16];
+  const CtxOff o = ctx_off(N, C);
+  if ((int)blockIdx.x < N) {
+    const int n = blockIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      double mi = ctx[o.mean_in + (int64_t)n * C + c], vi = ctx[o.var_in + (int64_t)n * C + c];
+      s1 += mi;
+      s2 += vi + mi * mi;
+    }
+    s1 = block_sum(s1, scratch);
+    s2 = block_sum(s2, scratch);
+    if (threadIdx.x == 0) {
+      double ml = s1 / C;
+      ctx[o.ln + 2 * n] = (float)ml;
+      ctx[o.ln + 2 * n + 1] = (float)(s2 / C - ml * ml);
+    }
+  } else {
+    const int c = (blockIdx.x - N) * 256 + threadIdx.x;
+    if (c < C) {
+      double s1 = 0, s2 = 0;
+      for (int n = 0; n < N; ++n) {
+        double mi = ctx[o.mean_in + (int64_t)n * C + c], vi = ctx[o.var_in + (int64_t)n * C + c];
+        s1 += mi;
+        s2 += vi + mi * mi;
+      }
+      pack[c] = (float)s1;
+      pack[C + c] = (float)s2;
+    }
+    if (blockIdx.x == (unsigned)N && threadIdx.x == 0) pack[2 * C] = (float)N;
+  }
+}
+
+__device__ __forceinline__ void softmax_k(const float* w, int K, float* out) {
+  float mx = w[0];
+  for (int i = 1; i < K; ++i) mx = fmaxf(mx, w[i]);
+  float e[3], s = 0.f;
+  for (int i = 0; i < K; ++i) { e[i] = expf(w[i] - mx); s += e[i]; }
+  for (int i = 0; i < 3; ++i) out[i] = i < K ? e[i] / s : 0.f;
+}
+
+__global__ __launch_bounds__(256) void sn_mix_b_kernel(float* __restrict__ ctx, const float* __restrict__ pack,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mw,
+                                                       const float* __restrict__ vw, float* __restrict__ rmean,
+                                                       float* __restrict__ rvar, int N, int C, float eps, float momentum,
+                                                       int training, int using_movavg, int using_bn) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)N * C) return;
+  const int n = (int)(i / C), c = (int)(i % C);
+  const CtxOff o = ctx_off(N, C);
+  const int K = using_bn ? 3 : 2;
+  float a[3], b[3];
+  softmax_k(mw, K, a);
+  softmax_k(vw, K, b);
+  const float mean_in = ctx[o.mean_in + i], var_in = ctx[o.var_in + i];
+  const float mean_ln = ctx[o.ln + 2 * n], var_ln = ctx[o.ln + 2 * n + 1];
+  float mean = a[0] * mean_in + a[1] * mean_ln;
+  float var = b[0] * var_in + b[1] * var_ln;
+  if (using_bn) {
+    float mean_bn, var_bn;
+    if (training) {
+      const float Ng = pack[2 * C];
+      mean_bn = pack[c] / Ng;
+      var_bn = pack[C + c] / Ng - mean_bn * mean_bn;
+      if (n == 0) {
+        if (using_movavg) {
+          rmean[c] = rmean[c] * momentum + (1.f - momentum) * mean_bn;
+          rvar[c] = rvar[c] * momentum + (1.f - momentum) * var_bn;
+        } else {
+          rmean[c] += mean_bn;
+          rvar[c] += mean_bn * mean_bn + var_bn;
+        }
+      }
+    } else {
+      mean_bn = rmean[c];
+      var_bn = rvar[c];
+    }
+    if (n == 0) {
+      ctx[o.bn + c] = mean_bn;
+      ctx[o.bn + C + c] = var_bn;
+    }
+    mean += a[2] * mean_bn;
+    var += b[2] * var_bn;
+  }
+  const float rstd = 1.0f / sqrtf(var + eps);
+  ctx[o.mean + i] = mean;
+  ctx[o.rstd + i] = rstd;
+  ctx[o.scale + i] = gamma[c] * rstd;
+}
+
+// ------------------------------------------------------------------------------------------- pass 2: normalise
+template <typename T, int V, bool RELU, bool RES>
+__global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                              int64_t ldy, const T* __restrict__ res, int64_t ldr,
+                                                              const float* __restrict__ ctx,
+                                                              const float* __restrict__ beta, int N, int64_t HW, int C,
+                                                              int PT, SnMap m) {
+  const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int64_t p0 = (int64_t)t * PT;
+  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  const CtxOff o = ctx_off(N, C);
+  const T* xn = x + (int64_t)n * HW * ldx;
+  T* yn = y + (int64_t)n * HW * ldy;
+  const T* rn = RES ? res + (int64_t)n * HW * ldr : nullptr;
+  const int cgl = tid % m.cgb, prow = tid / m.cgb;
+  if (tid >= m.active) return;
+  for (int cg0 = 0; cg0 < m.CG; cg0 += m.cgb) {
+    const int cg = cg0 + cgl;
+    if (cg >= m.CG) continue;
+    float mu[V], sc[V], be[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int64_t i = (int64_t)n * C + cg * V + v;
+      mu[v] = ctx[o.mean + i];
+      sc[v] = ctx[o.scale + i];
+      be[v] = beta[cg * V + v];
+    }
+    const int64_t co = (int64_t)cg * V;
+    int64_t p = p0 + prow;
+    for (; p + 3 * m.PR < p1; p += 4 * m.PR) {
+      float a[4][V];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Vec<T, V>::load(xn + (p + u * m.PR) * ldx + co, a[u]);
+      float r[4][V];
+      if (RES) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Vec<T, V>::load(rn + (p + u * m.PR) * ldr + co, r[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float z = fmaf(a[u][v] - mu[v], sc[v], be[v]);
+          if (RES) z += r[u][v];
+          a[u][v] = RELU ? fmaxf(z, 0.f) : z;
+        }
+        Vec<T, V>::store(yn + (p + u * m.PR) * ldy + co, a[u]);
+      }
+    }
+    for (; p < p1; p += m.PR) {
+      float a[V], r[V];
+      Vec<T, V>::load(xn + p * ldx + co, a);
+      if (RES) Vec<T, V>::load(rn + p * ldr + co, r);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float z = fmaf(a[v] - mu[v], sc[v], be[v]);
+        if (RES) z += r[v];
+        a[v] = RELU ? fmaxf(z, 0.f) : z;
+      }
+      Vec<T, V>::store(yn + p * ldy + co, a);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- backward pass 1
+template <typename T, int V, bool RELU, bool YMASK>
+__global__ __launch_bounds__(SN_THREADS) void sn_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy,
+                                                                   const T* __restrict__ x, int64_t ldx,
+                                                                   const T* __restrict__ ym, int64_t ldy,
+                                                                   const float* __restrict__ ctx,
+                                                                   const float* __restrict__ beta, int N, int64_t HW,
+                                                                   int C, int PT, int Tn, SnMap m,
+                                                                   float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int64_t p0 = (int64_t)t * PT;
+  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  const CtxOff o = ctx_off(N, C);
+  const T* xn = x + (int64_t)n * HW * ldx;
+  const T* dn = dy + (int64_t)n * HW * lddy;
+  const T* yn = YMASK ? ym + (int64_t)n * HW * ldy : nullptr;
+  const int cgl = tid % m.cgb, prow = tid / m.cgb;
+  const int row = m.cgb * V;
+  for (int cg0 = 0; cg0 < m.CG; cg0 += m.cgb) {
+    const int cg = cg0 + cgl;
+    const bool valid = tid < m.active && cg < m.CG;
+    float P[V], Q[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) P[v] = Q[v] = 0.f;
+    if (valid) {
+      float mu[V], sc[V], rs[V], be[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int64_t i = (int64_t)n * C + cg * V + v;
+        mu[v] = ctx[o.mean + i];
+        sc[v] = ctx[o.scale + i];
+        rs[v] = ctx[o.rstd + i];
+        be[v] = beta[cg * V + v];
+      }
+      const int64_t co = (int64_t)cg * V;
+      int64_t p = p0 + prow;
+      for (; p + m.PR < p1; p += 2 * m.PR) {
+        float a0[V], a1[V], g0[V], g1[V], y0[V], y1[V];
+        Vec<T, V>::load(xn + p * ldx + co, a0);
+        Vec<T, V>::load(xn + (p + m.PR) * ldx + co, a1);
+        Vec<T, V>::load(dn + p * lddy + co, g0);
+        Vec<T, V>::load(dn + (p + m.PR) * lddy + co, g1);
+        if (YMASK) {
+          Vec<T, V>::load(yn + p * ldy + co, y0);
+          Vec<T, V>::load(yn + (p + m.PR) * ldy + co, y1);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float e0 = a0[v] - mu[v], e1 = a1[v] - mu[v];
+          if (RELU) {
+            bool k0 = YMASK ? (y0[v] > 0.f) : (fmaf(e0, sc[v], be[v]) > 0.f);
+            bool k1 = YMASK ? (y1[v] > 0.f) : (fmaf(e1, sc[v], be[v]) > 0.f);
+            g0[v] = k0 ? g0[v] : 0.f;
+            g1[v] = k1 ? g1[v] : 0.f;
+          }
+          P[v] += g0[v] + g1[v];
+          Q[v] += g0[v] * (e0 * rs[v]) + g1[v] * (e1 * rs[v]);
+        }
+      }
+      for (; p < p1; p += m.PR) {
+        float a0[V], g0[V], y0[V];
+        Vec<T, V>::load(xn + p * ldx + co, a0);
+        Vec<T, V>::load(dn + p * lddy + co, g0);
+        if (YMASK) Vec<T, V>::load(yn + p * ldy + co, y0);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float e0 = a0[v] - mu[v];
+          if (RELU) {
+            bool k0 = YMASK ? (y0[v] > 0.f) : (fmaf(e0, sc[v], be[v]) > 0.f);
+            g0[v] = k0 ? g0[v] : 0.f;
+          }
+          P[v] += g0[v];
+          Q[v] += g0[v] * (e0 * rs[v]);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < m.active) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        red[prow * row + cgl * V + v] = P[v];
+        red[m.PR * row + prow * row + cgl * V + v] = Q[v];
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < row; j += SN_THREADS) {
+      const int ch = cg0 * V + j;
+      if (ch < C) {
+        float s = 0.f, q = 0.f;
+        for (int r = 0; r < m.PR; ++r) {
+          s += red[r * row + j];
+          q += red[m.PR * row + r * row + j];
+        }
+        float* op = part + (((int64_t)n * Tn + t) * C + ch) * 2;
+        op[0] = s;
+        op[1] = q;
+      }
+    }
+  }
+}
+
+// partials -> P, Q, dm, dv per (n,c)
+__global__ __launch_bounds__(512) void sn_bwd_mix_a1_kernel(const float* __restrict__ part, int T,
+                                                            const float* __restrict__ ctx,
+                                                            const float* __restrict__ gamma, float* __restrict__ ctxb,
+                                                            int N, int C) {
+  __shared__ double red[2][8][64];
+  const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
+  double P = 0, Q = 0;
+  if (c < C) {
+    for (int t = tl; t < T; t += 8) {
+      const float* p = part + (((int64_t)n * T + t) * C + c) * 2;
+      P += (double)p[0];
+      Q += (double)p[1];
+    }
+  }
+  red[0][tl][cl] = P;
+  red[1][tl][cl] = Q;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    P = 0; Q = 0;
+    for (int i = 0; i < 8; ++i) { P += red[0][i][cl]; Q += red[1][i][cl]; }
+    const CtxOff o = ctx_off(N, C);
+    const CtxbOff ob = ctxb_off(N, C);
+    const int64_t i = (int64_t)n * C + c;
+    const double r = ctx[o.rstd + i], g = gamma[c];
+    ctxb[ob.P + i] = (float)P;
+    ctxb[ob.Q + i] = (float)Q;
+    ctxb[ob.dm + i] = (float)(-r * g * P);
+    ctxb[ob.dv + i] = (float)(-0.5 * r * r * g * Q);
+  }
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_mix_a2_kernel(float* __restrict__ ctxb, float* __restrict__ packb,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                            int C) {
+  __shared__ double scratch[16];
+  const CtxbOff ob = ctxb_off(N, C);
+  if ((int)blockIdx.x < N) {
+    const int n = blockIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      s1 += (double)ctxb[ob.dm + (int64_t)n * C + c];
+      s2 += (double)ctxb[ob.dv + (int64_t)n * C + c];
+    }
+    s1 = block_sum(s1, scratch);
+    s2 = block_sum(s2, scratch);
+    if (threadIdx.x == 0) {
+      ctxb[ob.lnb + 2 * n] = (float)s1;
+      ctxb[ob.lnb + 2 * n + 1] = (float)s2;
+    }
+  } else {
+    const int c = (blockIdx.x - N) * 256 + threadIdx.x;
+    if (c < C) {
+      double s1 = 0, s2 = 0, sp = 0, sq = 0;
+      for (int n = 0; n < N; ++n) {
+        const int64_t i = (int64_t)n * C + c;
+        s1 += (double)ctxb[ob.dm + i];
+        s2 += (double)ctxb[ob.dv + i];
+        sp += (double)ctxb[ob.P + i];
+        sq += (double)ctxb[ob.Q + i];
+      }
+      packb[c] = (float)s1;
+      packb[C + c] = (float)s2;
+      dgamma[c] = (float)sq;
+      dbeta[c] = (float)sp;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restrict__ ctx, float* __restrict__ ctxb,
+                                                            const float* __restrict__ packb,
+                                                            const float* __restrict__ mw, const float* __restrict__ vw,
+                                                            float* __restrict__ dmw, float* __restrict__ dvw, int N,
+                                                            int64_t HW, int C, float Ng, int training, int using_bn) {
+  __shared__ double scratch[16];
+  const CtxOff o = ctx_off(N, C);
+  const CtxbOff ob = ctxb_off(N, C);
+  const int K = using_bn ? 3 : 2;
+  float a[3], b[3];
+  softmax_k(mw, K, a);
+  softmax_k(vw, K, b);
+  const bool bn_batch = using_bn && training;
+  double da[3] = {0, 0, 0}, db[3] = {0, 0, 0};
+  const int64_t NC = (int64_t)N * C;
+  for (int64_t i = threadIdx.x; i < NC; i += 1024) {
+    const int n = (int)(i / C), c = (int)(i % C);
+    const float dm = ctxb[ob.dm + i], dv = ctxb[ob.dv + i];
+    const float mean_in = ctx[o.mean_in + i], var_in = ctx[o.var_in + i];
+    const float mean_ln = ctx[o.ln + 2 * n], var_ln = ctx[o.ln + 2 * n + 1];
+    da[0] += (double)dm * mean_in;
+    da[1] += (double)dm * mean_ln;
+    db[0] += (double)dv * var_in;
+    db[1] += (double)dv * var_ln;
+    const float dvar_ln = b[1] * ctxb[ob.lnb + 2 * n + 1];
+    const float dmean_ln = a[1] * ctxb[ob.lnb + 2 * n] - 2.f * mean_ln * dvar_ln;
+    float dtemp = dvar_ln / C;
+    float dmean_in = a[0] * dm + dmean_ln / C;
+    if (using_bn) {
+      const float mean_bn = ctx[o.bn + c], var_bn = ctx[o.bn + C + c];
+      da[2] += (double)dm * mean_bn;
+      db[2] += (double)dv * var_bn;
+      if (bn_batch) {
+        const float dvar_bn = b[2] * packb[C + c];
+        const float dmean_bn = a[2] * packb[c] - 2.f * mean_bn * dvar_bn;
+        dtemp += dvar_bn / Ng;
+        dmean_in += dmean_bn / Ng;
+      }
+    }
+    const float dvar_in = b[0] * dv + dtemp;
+    dmean_in += 2.f * mean_in * dtemp;
+    const float B = 2.f * dvar_in / (float)(HW - 1);
+    ctxb[ob.B + i] = B;
+    ctxb[ob.K + i] = dmean_in / (float)HW - B * mean_in;
+  }
+  for (int k = 0; k < 3; ++k) {
+    da[k] = block_sum(da[k], scratch);
+    db[k] = block_sum(db[k], scratch);
+  }
+  if (threadIdx.x == 0) {
+    double sa = 0, sb = 0;
+    for (int k = 0; k < K; ++k) { sa += a[k] * da[k]; sb += b[k] * db[k]; }
+    for (int k = 0; k < K; ++k) {
+      dmw[k] = (float)(a[k] * (da[k] - sa));
+      dvw[k] = (float)(b[k] * (db[k] - sb));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- backward pass 2
+template <typename T, int V, bool RELU, bool YMASK>
+__global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy,
+                                                                  const T* __restrict__ x, int64_t ldx,
+                                                                  const T* __restrict__ ym, int64_t ldy,
+                                                                  T* __restrict__ dx, int64_t lddx,
+                                                                  const float* __restrict__ ctx,
+                                                                  const float* __restrict__ ctxb,
+                                                                  const float* __restrict__ beta, int N, int64_t HW,
+                                                                  int C, int PT, SnMap m) {
+  const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int64_t p0 = (int64_t)t * PT;
+  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  const CtxOff o = ctx_off(N, C);
+  const CtxbOff ob = ctxb_off(N, C);
+  const T* xn = x + (int64_t)n * HW * ldx;
+  const T* dn = dy + (int64_t)n * HW * lddy;
+  const T* yn = YMASK ? ym + (int64_t)n * HW * ldy : nullptr;
+  T* on = dx + (int64_t)n * HW * lddx;
+  const int cgl = tid % m.cgb, prow = tid / m.cgb;
+  if (tid >= m.active) return;
+  for (int cg0 = 0; cg0 < m.CG; cg0 += m.cgb) {
+    const int cg = cg0 + cgl;
+    if (cg >= m.CG) continue;
+    float mu[V], sc[V], be[V], Bc[V], Kc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int64_t i = (int64_t)n * C + cg * V + v;
+      mu[v] = ctx[o.mean + i];
+      sc[v] = ctx[o.scale + i];
+      be[v] = beta[cg * V + v];
+      Bc[v] = ctxb[ob.B + i];
+      Kc[v] = ctxb[ob.K + i];
+    }
+    const int64_t co = (int64_t)cg * V;
+    int64_t p = p0 + prow;
+    for (; p + m.PR < p1; p += 2 * m.PR) {
+      float a0[V], a1[V], g0[V], g1[V], y0[V], y1[V];
+      Vec<T, V>::load(xn + p * ldx + co, a0);
+      Vec<T, V>::load(xn + (p + m.PR) * ldx + co, a1);
+      Vec<T, V>::load(dn + p * lddy + co, g0);
+      Vec<T, V>::load(dn + (p + m.PR) * lddy + co, g1);
+      if (YMASK) {
+        Vec<T, V>::load(yn + p * ldy + co, y0);
+        Vec<T, V>::load(yn + (p + m.PR) * ldy + co, y1);
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        if (RELU) {
+          bool k0 = YMASK ? (y0[v] > 0.f) : (fmaf(a0[v] - mu[v], sc[v], be[v]) > 0.f);
+          bool k1 = YMASK ? (y1[v] > 0.f) : (fmaf(a1[v] - mu[v], sc[v], be[v]) > 0.f);
+          g0[v] = k0 ? g0[v] : 0.f;
+          g1[v] = k1 ? g1[v] : 0.f;
+        }
+        g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
+        g1[v] = fmaf(sc[v], g1[v], fmaf(Bc[v], a1[v], Kc[v]));
+      }
+      Vec<T, V>::store(on + p * lddx + co, g0);
+      Vec<T, V>::store(on + (p + m.PR) * lddx + co, g1);
+    }
+    for (; p < p1; p += m.PR) {
+      float a0[V], g0[V], y0[V];
+      Vec<T, V>::load(xn + p * ldx + co, a0);
+      Vec<T, V>::load(dn + p * lddy + co, g0);
+      if (YMASK) Vec<T, V>::load(yn + p * ldy + co, y0);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        if (RELU) {
+          bool k0 = YMASK ? (y0[v] > 0.f) : (fmaf(a0[v] - mu[v], sc[v], be[v]) > 0.f);
+          g0[v] = k0 ? g0[v] : 0.f;
+        }
+        g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
+      }
+      Vec<T, V>::store(on + p * lddx + co, g0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- host side
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+constexpr int full_vec() { return 16 / sizeof(T); }
+
+// can every tensor in the call be accessed 16 bytes at a time?
+template <typename T>
+bool can_vec(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+  const int V = full_vec<T>();
+  if (C % V) return false;
+  for (const void* p : ptrs)
+    if (p && !aligned16(p)) return false;
+  for (int64_t l : lds)
+    if (l % V) return false;
+  return true;
+}
+
+#define SN_COMMON_CHECKS(fn)                                                                       \
+  SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1, fn ": N, C, HW must be positive (N=%d C=%d HW=%lld)", N, C, \
+                 (long long)HW);                                                                   \
+  SNWS_CHECK_ARG(dtype == SNWS_F32 || dtype == SNWS_BF16, fn ": dtype %d is not F32/BF16", dtype);
+
+template <typename T, int V>
+int run_stats(const void* x, int N, int64_t HW, int C, int64_t ldx, float* part, float* shift, hipStream_t st) {
+  const SnMap m = sn_map(C, V);
+  const int T_ = sn_tiles(N, HW, C);
+  const int PT = (int)cdiv64(HW, T_);
+  const size_t lds = (size_t)2 * m.PR * m.cgb * V * sizeof(float);
+  sn_stats_kernel<T, V><<<dim3(T_, N), SN_THREADS, lds, st>>>((const T*)x, HW, C, ldx, PT, T_, m, part, shift);
+  SNWS_LAUNCH_CHECK("snws_sn_stats");
+  return SNWS_OK;
+}
+
+template <typename T, int V>
+int run_apply(const void* x, int64_t ldx, void* y, int64_t ldy, const void* res, int64_t ldr, const float* ctx,
+              const float* beta, int N, int64_t HW, int C, int relu, hipStream_t st) {
+  const SnMap m = sn_map(C, V);
+  const int T_ = sn_tiles(N, HW, C);
+  const int PT = (int)cdiv64(HW, T_);
+  dim3 grid(T_, N);
+#define AP(R, S) sn_apply_kernel<T, V, R, S><<<grid, SN_THREADS, 0, st>>>((const T*)x, ldx, (T*)y, ldy, (const T*)res, ldr, ctx, beta, N, HW, C, PT, m)
+  if (relu) { if (res) AP(true, true); else AP(true, false); }
+  else { if (res) AP(false, true); else AP(false, false); }
+#undef AP
+  SNWS_LAUNCH_CHECK("snws_sn_apply");
+  return SNWS_OK;
+}
+
+template <typename T, int V>
+int run_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* ym, int64_t ldy,
+                   const float* ctx, const float* beta, int N, int64_t HW, int C, int relu, float* part,
+                   hipStream_t st) {
+  const SnMap m = sn_map(C, V);
+  const int T_ = sn_tiles(N, HW, C);
+  const int PT = (int)cdiv64(HW, T_);
+  const size_t lds = (size_t)2 * m.PR * m.cgb * V * sizeof(float);
+  dim3 grid(T_, N);
+#define BR(R, Y) sn_bwd_reduce_kernel<T, V, R, Y><<<grid, SN_THREADS, lds, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, ctx, beta, N, HW, C, PT, T_, m, part)
+  if (relu) { if (ym) BR(true, true); else BR(true, false); }
+  else BR(false, false);
+#undef BR
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_reduce");
+  return SNWS_OK;
+}
+
+template <typename T, int V>
+int run_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* ym, int64_t ldy, void* dx,
+                  int64_t lddx, const float* ctx, const float* ctxb, const float* beta, int N, int64_t HW, int C,
+                  int relu, hipStream_t st) {
+  const SnMap m = sn_map(C, V);
+  const int T_ = sn_tiles(N, HW, C);
+  const int PT = (int)cdiv64(HW, T_);
+  dim3 grid(T_, N);
+#define BA(R, Y) sn_bwd_apply_kernel<T, V, R, Y><<<grid, SN_THREADS, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, (T*)dx, lddx, ctx, ctxb, beta, N, HW, C, PT, m)
+  if (relu) { if (ym) BA(true, true); else BA(true, false); }
+  else BA(false, false);
+#undef BA
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_apply");
+  return SNWS_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t snws_sn_ctx_floats(int N, int C) { return ctx_off(N, C).total; }
+extern "C" int64_t snws_sn_ctxb_floats(int N, int C) { return ctxb_off(N, C).total; }
+extern "C" int snws_sn_stats_tiles(int N, int64_t HW, int C) { return sn_tiles(N, HW, C); }
+
+extern "C" int snws_sn_stats(const void* x, int dtype, int N, int64_t HW, int C, int64_t ldx, float* part,
+                             float* shift, void* stream) {
+  SN_COMMON_CHECKS("snws_sn_stats");
+  SNWS_CHECK_ARG(x && part && shift, "snws_sn_stats: NULL pointer");
+  SNWS_CHECK_ARG(ldx >= C, "snws_sn_stats: ldx %lld < C %d", (long long)ldx, C);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SNWS_F32) {
+    if (can_vec<float>(C, {x}, {ldx})) return run_stats<float, 4>(x, N, HW, C, ldx, part, shift, st);
+    return run_stats<float, 1>(x, N, HW, C, ldx, part, shift, st);
+  }
+  if (can_vec<bf16_t>(C, {x}, {ldx})) return run_stats<bf16_t, 8>(x, N, HW, C, ldx, part, shift, st);
+  return run_stats<bf16_t, 1>(x, N, HW, C, ldx, part, shift, st);
+}
+
+extern "C" int snws_sn_finalize(const float* part, int T, const float* shift, int shift_per_image, int N, int64_t HW,
+                                int C, float* ctx, void* stream) {
+  SNWS_CHECK_ARG(part && shift && ctx, "snws_sn_finalize: NULL pointer");
+  SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1 && T >= 1, "snws_sn_finalize: bad sizes");
+  sn_finalize_kernel<<<dim3(cdiv(C, 64), N), 512, 0, (hipStream_t)stream>>>(part, T, shift, shift_per_image, N, HW, C,
+                                                                          ctx);
+  SNWS_LAUNCH_CHECK("snws_sn_finalize");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_mix_a(float* ctx, float* pack, int N, int C, void* stream) {
+  SNWS_CHECK_ARG(ctx && pack, "snws_sn_mix_a: NULL pointer");
+  SNWS_CHECK_ARG(N >= 1 && C >= 1, "snws_sn_mix_a: bad sizes");
+  sn_mix_a_kernel<<<N + cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(ctx, pack, N, C);
+  SNWS_LAUNCH_CHECK("snws_sn_mix_a");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_mix_b(float* ctx, const float* pack, const float* gamma, const float* mean_weight,
+                             const float* var_weight, float* running_mean, float* running_var, int N, int C, float eps,
+                             float momentum, int training, int using_movavg, int using_bn, void* stream) {
+  SNWS_CHECK_ARG(ctx && gamma && mean_weight && var_weight, "snws_sn_mix_b: NULL pointer");
+  SNWS_CHECK_ARG(!using_bn || (running_mean && running_var), "snws_sn_mix_b: using_bn needs the running buffers");
+  SNWS_CHECK_ARG(!(using_bn && training) || pack, "snws_sn_mix_b: training with using_bn needs pack");
+  SNWS_CHECK_ARG(N >= 1 && C >= 1, "snws_sn_mix_b: bad sizes");
+  sn_mix_b_kernel<<<(unsigned)cdiv64((int64_t)N * C, 256), 256, 0, (hipStream_t)stream>>>(
+      ctx, pack, gamma, mean_weight, var_weight, running_mean, running_var, N, C, eps, momentum, training,
+      using_movavg, using_bn);
+  SNWS_LAUNCH_CHECK("snws_sn_mix_b");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_apply(const void* x, int64_t ldx, void* y, int64_t ldy, const void* residual, int64_t ldr,
+                             int dtype, const float* ctx, const float* beta, int N, int64_t HW, int C, int relu,
+                             void* stream) {
+  SN_COMMON_CHECKS("snws_sn_apply");
+  SNWS_CHECK_ARG(x && y && ctx && beta, "snws_sn_apply: NULL pointer");
+  SNWS_CHECK_ARG(ldx >= C && ldy >= C && (!residual || ldr >= C), "snws_sn_apply: pixel stride smaller than C");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SNWS_F32) {
+    if (can_vec<float>(C, {x, y, residual}, {ldx, ldy, residual ? ldr : 0}))
+      return run_apply<float, 4>(x, ldx, y, ldy, residual, ldr, ctx, beta, N, HW, C, relu, st);
+    return run_apply<float, 1>(x, ldx, y, ldy, residual, ldr, ctx, beta, N, HW, C, relu, st);
+  }
+  if (can_vec<bf16_t>(C, {x, y, residual}, {ldx, ldy, residual ? ldr : 0}))
+    return run_apply<bf16_t, 8>(x, ldx, y, ldy, residual, ldr, ctx, beta, N, HW, C, relu, st);
+  return run_apply<bf16_t, 1>(x, ldx, y, ldy, residual, ldr, ctx, beta, N, HW, C, relu, st);
+}
+
+extern "C" int snws_sn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask,
+                                  int64_t ldy, int dtype, const float* ctx, const float* gamma, const float* beta, int N,
+                                  int64_t HW, int C, int relu, float* part, void* stream) {
+  SN_COMMON_CHECKS("snws_sn_bwd_reduce");
+  (void)gamma;
+  SNWS_CHECK_ARG(dy && x && ctx && beta && part, "snws_sn_bwd_reduce: NULL pointer");
+  SNWS_CHECK_ARG(lddy >= C && ldx >= C && (!y_for_mask || ldy >= C), "snws_sn_bwd_reduce: pixel stride smaller than C");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SNWS_F32) {
+    if (can_vec<float>(C, {dy, x, y_for_mask}, {lddy, ldx, y_for_mask ? ldy : 0}))
+      return run_bwd_reduce<float, 4>(dy, lddy, x, ldx, y_for_mask, ldy, ctx, beta, N, HW, C, relu, part, st);
+    return run_bwd_reduce<float, 1>(dy, lddy, x, ldx, y_for_mask, ldy, ctx, beta, N, HW, C, relu, part, st);
+  }
+  if (can_vec<bf16_t>(C, {dy, x, y_for_mask}, {lddy, ldx, y_for_mask ? ldy : 0}))
+    return run_bwd_reduce<bf16_t, 8>(dy, lddy, x, ldx, y_for_mask, ldy, ctx, beta, N, HW, C, relu, part, st);
+  return run_bwd_reduce<bf16_t, 1>(dy, lddy, x, ldx, y_for_mask, ldy, ctx, beta, N, HW, C, relu, part, st);
+}
+
+extern "C" int snws_sn_bwd_mix_a(const float* part, int T, const float* ctx, const float* gamma, float* ctxb,
+                                 float* packb, float* dgamma, float* dbeta, int N, int C, void* stream) {
+  SNWS_CHECK_ARG(part && ctx && gamma && ctxb && packb && dgamma && dbeta, "snws_sn_bwd_mix_a: NULL pointer");
+  SNWS_CHECK_ARG(N >= 1 && C >= 1 && T >= 1, "snws_sn_bwd_mix_a: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  sn_bwd_mix_a1_kernel<<<dim3(cdiv(C, 64), N), 512, 0, st>>>(part, T, ctx, gamma, ctxb, N, C);
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_a(1)");
+  sn_bwd_mix_a2_kernel<<<N + cdiv(C, 256), 256, 0, st>>>(ctxb, packb, dgamma, dbeta, N, C);
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_a(2)");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_bwd_mix_b(const float* ctx, float* ctxb, const float* packb, const float* mean_weight,
+                                 const float* var_weight, const float* running_mean, const float* running_var,
+                                 float* dmean_weight, float* dvar_weight, int N, int64_t HW, int C, float n_global,
+                                 int training, int using_bn, void* stream) {
+  (void)running_mean;
+  (void)running_var;
+  SNWS_CHECK_ARG(ctx && ctxb && packb && mean_weight && var_weight && dmean_weight && dvar_weight,
+                 "snws_sn_bwd_mix_b: NULL pointer");
+  SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1 && n_global >= 1.f, "snws_sn_bwd_mix_b: bad sizes");
+  sn_bwd_mix_b_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ctx, ctxb, packb, mean_weight, var_weight, dmean_weight,
+                                                         dvar_weight, N, HW, C, n_global, training, using_bn);
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_b");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask,
+                                 int64_t ldy, void* dx, int64_t lddx, int dtype, const float* ctx, const float* ctxb,
+                                 const float* beta, int N, int64_t HW, int C, int relu, void* stream) {
+  SN_COMMON_CHECKS("snws_sn_bwd_apply");
+  SNWS_CHECK_ARG(dy && x && dx && ctx && ctxb && beta, "snws_sn_bwd_apply: NULL pointer");
+  SNWS_CHECK_ARG(lddy >= C && ldx >= C && lddx >= C && (!y_for_mask || ldy >= C),
+                 "snws_sn_bwd_apply: pixel stride smaller than C");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SNWS_F32) {
+    if (can_vec<float>(C, {dy, x, y_for_mask, dx}, {lddy, ldx, y_for_mask ? ldy : 0, lddx}))
+      return run_bwd_apply<float, 4>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st);
+    return run_bwd_apply<float, 1>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st);
+  }
+  if (can_vec<bf16_t>(C, {dy, x, y_for_mask, dx}, {lddy, ldx, y_for_mask ? ldy : 0, lddx}))
+    return run_bwd_apply<bf16_t, 8>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st);
+  return run_bwd_apply<bf16_t, 1>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st);
+}

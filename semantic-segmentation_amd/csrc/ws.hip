@@ -1,0 +1,137 @@
+// Weight standardisation (replaces modeling/weightstd.py:13-17 of the reference and its autograd).
+//
+// One workgroup per output channel: the fan-in (I*kh*kw <= a few thousand floats) is read once into registers,
+// mean and unbiased std are exact two-pass f64 reductions, and the standardized filter is written in every
+// layout its consumers want: f32 OIHW / OHWI for the direct kernels and the bf16 MFMA operand images
+// (forward, and flipped + transposed for dgrad).  HBM-bound: 4 B read + <= 12 B written per parameter.
+#include "common.h"
+#include "pack.h"
+
+namespace {
+
+constexpr int WS_THREADS = 256;
+constexpr int WS_MAX_PER_THREAD = 64;  // fan-in up to 16384
+
+__global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restrict__ w, int O, int I, int kh, int kw,
+                                                            float* __restrict__ what_oihw,
+                                                            float* __restrict__ what_ohwi, bf16_t* __restrict__ pk_fwd,
+                                                            bf16_t* __restrict__ pk_dgrad) {
+  __shared__ double scratch[16];
+  const int o = blockIdx.x;
+  const int taps = kh * kw, n = I * taps;
+  const float* wo = w + (int64_t)o * n;
+  float v[WS_MAX_PER_THREAD];
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+    const int i = threadIdx.x + k * WS_THREADS;
+    v[k] = i < n ? wo[i] : 0.f;
+    s += v[k];
+  }
+  const float mu = (float)(block_sum(s, scratch) / n);
+  double ss = 0;
+#pragma unroll
+  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+    const int i = threadIdx.x + k * WS_THREADS;
+    v[k] = i < n ? v[k] - mu : 0.f;
+    ss += (double)v[k] * v[k];
+  }
+  const float sd = (float)sqrt(block_sum(ss, scratch) / (n - 1)) + 1e-5f;
+  const PackGeom gf = pack_geom(I, O, taps);   // forward image: contraction over input channels
+  const PackGeom gd = pack_geom(O, I, taps);   // dgrad image: contraction over output channels
+#pragma unroll
+  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+    const int i = threadIdx.x + k * WS_THREADS;
+    if (i >= n) break;
+    const float h = v[k] / sd;
+    const int ci = i / taps, tap = i % taps;
+    if (what_oihw) what_oihw[(int64_t)o * n + i] = h;
+    if (what_ohwi) what_ohwi[((int64_t)o * taps + tap) * I + ci] = h;
+    if (pk_fwd) pk_fwd[pack_index(gf, o, ci, tap)] = (bf16_t)h;
+    if (pk_dgrad) pk_dgrad[pack_index(gd, ci, o, taps - 1 - tap)] = (bf16_t)h;
+  }
+}
+
+__global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restrict__ w, const float* __restrict__ g,
+                                                            int64_t ldg, float* __restrict__ dw, int O, int I, int kh,
+                                                            int kw) {
+  __shared__ double scratch[16];
+  const int o = blockIdx.x;
+  const int taps = kh * kw, n = I * taps;
+  const float* wo = w + (int64_t)o * n;
+  float c[WS_MAX_PER_THREAD], gg[WS_MAX_PER_THREAD];
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+    const int i = threadIdx.x + k * WS_THREADS;
+    c[k] = i < n ? wo[i] : 0.f;
+    s += c[k];
+  }
+  const float mu = (float)(block_sum(s, scratch) / n);
+  double ss = 0, gc = 0;
+#pragma unroll
+  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+    const int i = threadIdx.x + k * WS_THREADS;
+    if (i < n) {
+      const int ci = i / taps, tap = i % taps;
+      c[k] -= mu;
+      gg[k] = g[((int64_t)o * taps + tap) * ldg + ci];
+    } else {
+      c[k] = 0.f;
+      gg[k] = 0.f;
+    }
+    ss += (double)c[k] * c[k];
+    gc += (double)gg[k] * c[k];
+  }
+  const double sdev = sqrt(block_sum(ss, scratch) / (n - 1));
+  gc = block_sum(gc, scratch);
+  const double d = sdev + 1e-5;
+  const double k2 = gc / (d * d * (n - 1) * sdev);
+  double ts = 0;
+#pragma unroll
+  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+    const int i = threadIdx.x + k * WS_THREADS;
+    const double t = i < n ? (double)gg[k] / d - k2 * c[k] : 0.0;
+    gg[k] = (float)t;
+    ts += t;
+  }
+  const float tm = (float)(block_sum(ts, scratch) / n);
+#pragma unroll
+  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+    const int i = threadIdx.x + k * WS_THREADS;
+    if (i < n) dw[(int64_t)o * n + i] = gg[k] - tm;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t snws_conv_pack_bytes(int c_in, int c_out, int kh, int kw) {
+  if (c_in < 1 || c_out < 1 || kh < 1 || kw < 1) return 0;
+  const PackGeom g = pack_geom(c_in, c_out, kh * kw);
+  return pack_elems(g) * 2;
+}
+
+extern "C" int snws_ws_fwd(const float* w, int O, int I, int kh, int kw, float* what_oihw, float* what_ohwi,
+                           void* pack_fwd, void* pack_dgrad, void* stream) {
+  SNWS_CHECK_ARG(w, "snws_ws_fwd: w is NULL");
+  SNWS_CHECK_ARG(O >= 1 && I >= 1 && kh >= 1 && kw >= 1, "snws_ws_fwd: bad shape (%d,%d,%d,%d)", O, I, kh, kw);
+  const int64_t n = (int64_t)I * kh * kw;
+  SNWS_CHECK_ARG(n >= 2, "snws_ws_fwd: fan-in %lld < 2 has no unbiased std", (long long)n);
+  if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_ws_fwd: fan-in %lld > %d", (long long)n, WS_THREADS * WS_MAX_PER_THREAD);
+  ws_fwd_kernel<<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, O, I, kh, kw, what_oihw, what_ohwi, (bf16_t*)pack_fwd,
+                                                         (bf16_t*)pack_dgrad);
+  SNWS_LAUNCH_CHECK("snws_ws_fwd");
+  return SNWS_OK;
+}
+
+extern "C" int snws_ws_bwd(const float* w, const float* g_ohwi, int64_t ldg, float* dw, int O, int I, int kh, int kw,
+                           void* stream) {
+  SNWS_CHECK_ARG(w && g_ohwi && dw, "snws_ws_bwd: NULL pointer");
+  SNWS_CHECK_ARG(O >= 1 && I >= 1 && kh >= 1 && kw >= 1 && ldg >= I, "snws_ws_bwd: bad shape");
+  const int64_t n = (int64_t)I * kh * kw;
+  SNWS_CHECK_ARG(n >= 2, "snws_ws_bwd: fan-in %lld < 2", (long long)n);
+  if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_ws_bwd: fan-in %lld too large", (long long)n);
+  ws_bwd_kernel<<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, g_ohwi, ldg, dw, O, I, kh, kw);
+  SNWS_LAUNCH_CHECK("snws_ws_bwd");
+  return SNWS_OK;
+}

@@ -1,0 +1,62 @@
+"""Building blocks shared by the SNws model graphs."""
+import torch
+import torch.nn as nn
+
+import modeling.snorm as sn
+import modeling.weightstd as ws
+from snws import ops
+
+
+class ConvSnRelu(nn.Sequential):
+    """Conv2dws -> SwitchNorm2d -> ReLU with the reference's layout (Sequential indices 0/1/2, so state_dict
+    keys read '<name>.0.weight', '<name>.1.running_mean', ... as produced by ConvSnRelu at
+    modeling/UNet3p_SNws.py:29-33), executed as ONE fused op: the conv epilogue emits the per-channel partial
+    moments SwitchNorm needs, SwitchNorm applies the ReLU, and backward recomputes the ReLU mask from the conv
+    output instead of storing the activation twice."""
+
+    def __init__(self, in_channels, out_channels, using_movavg=True, using_bn=True, last_gamma=False, kernel_size=3,
+                 stride=1, padding=1):
+        super(ConvSnRelu, self).__init__(
+            ws.Conv2dws(in_channels, out_channels, kernel_size, stride, padding),
+            sn.SwitchNorm2d(out_channels, using_movavg=using_movavg, using_bn=using_bn, last_gamma=last_gamma),
+            nn.ReLU())
+
+    def forward(self, x):
+        conv, norm = self[0], self[1]
+        if x.dim() != 4:
+            raise ValueError('expected 4D input (got {}D input)'.format(x.dim()))
+        ops.require_gpu(x, "ConvSnRelu")
+        prep = conv.prepared(x.dtype == torch.bfloat16 and not conv.force_direct)
+        if conv.force_direct:
+            y = ops.Conv2dwsFn.apply(x, conv.weight, conv.bias, prep, True)
+            return ops.SwitchNormFn.apply(y, norm.weight, norm.bias, norm.mean_weight, norm.var_weight,
+                                          ops.SNParams(norm), True)
+        return ops.ConvSnReluFn.apply(x, conv.weight, conv.bias, norm.weight, norm.bias, norm.mean_weight,
+                                      norm.var_weight, prep, ops.SNParams(norm), True)
+
+
+def crop_concat(a, b):
+    """Centre-crop skip `a` to b's spatial size (diff//2 from the top/left) and stack (a, b) on the channel axis
+    (CropConcat, modeling/UNet_SNws.py:35-39)."""
+    dy = a.size(2) - b.size(2)
+    dx = a.size(3) - b.size(3)
+    if dy or dx:
+        a = a[:, :, dy // 2: a.size(2) - (dy - dy // 2), dx // 2: a.size(3) - (dx - dx // 2)]
+    return torch.cat((a, b), dim=1)
+
+
+def to_device_layout(x, dtype=None):
+    """Input images (N,C,H,W) -> channels-last tensor of the compute dtype."""
+    if dtype is not None and x.dtype != dtype:
+        x = x.to(dtype)
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def head_conv(conv, x):
+    """The plain nn.Conv2d classification head (modeling/UNet3p_SNws.py:93,158) on a compute-dtype activation:
+    run in the activation's dtype (bf16 GEMM on the matrix cores), return float32 logits."""
+    if x.dtype == conv.weight.dtype:
+        return torch.nn.functional.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding)
+    w = conv.weight.to(x.dtype)
+    b = None if conv.bias is None else conv.bias.to(x.dtype)
+    return torch.nn.functional.conv2d(x, w, b, conv.stride, conv.padding).float()

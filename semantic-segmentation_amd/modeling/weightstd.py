@@ -1,0 +1,40 @@
+"""Weight-standardized convolution, same module API as the reference's modeling/weightstd.py:8-18.
+
+`Conv2dws` is an `nn.Conv2d` subclass with the reference's constructor signature and state_dict
+(`weight`, `bias`).  forward() standardizes the filter per output channel (mean 0, unbiased std 1 over the
+fan-in, eps 1e-5 added to the std) and convolves, all in HIP kernels for gfx950: a one-pass standardize +
+operand-pack kernel, then the bf16 MFMA implicit-GEMM kernels for 3x3/1x1 stride-1 "same" convolutions, or the
+direct kernels for every other stride / padding / dilation / groups combination and for float32.
+There is no CPU path: a CPU tensor raises.
+"""
+import torch.nn as nn
+
+from snws import ops
+
+
+class Conv2dws(nn.Conv2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+        super(Conv2dws, self).__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        self._prep = None
+        self._prep_key = None
+        self.force_direct = False   # True pins the exact direct kernels (float32 tier / debugging)
+
+    def prepared(self, want_mfma):
+        """Standardized filter images, rebuilt only when the master weight changed (optimizer steps and
+        load_state_dict bump the tensor's version counter), so a module shared by several call sites in one
+        forward standardizes once."""
+        w = self.weight
+        key = (w._version, w.data_ptr(), w.device, bool(want_mfma))
+        if self._prep is None or self._prep_key != key:
+            cfg = ops.ConvCfg(w.shape, self.stride, self.padding, self.dilation, self.groups)
+            self._prep = ops.PreparedWeight(w, cfg, want_mfma)
+            self._prep_key = key
+        return self._prep
+
+    def forward(self, x):
+        if x.dim() != 4:
+            raise ValueError('expected 4D input (got {}D input)'.format(x.dim()))
+        ops.require_gpu(x, "Conv2dws")
+        import torch
+        prep = self.prepared(x.dtype == torch.bfloat16 and not self.force_direct)
+        return ops.Conv2dwsFn.apply(x, self.weight, self.bias, prep, self.force_direct)

@@ -1,0 +1,99 @@
+"""ctypes binding of libsnws.so (the C ABI declared in include/snws.h).
+
+The library is built in-tree (semantic-segmentation_amd/lib/libsnws.so) by __graft_entry__.build() or
+`make -C semantic-segmentation_amd/csrc`.  There is NO fallback: if the library is missing, or a call
+returns a non-zero status, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER, Structure
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsnws.so")
+
+SNWS_F32, SNWS_BF16, SNWS_F64, SNWS_I64, SNWS_I32, SNWS_U8 = 0, 1, 2, 3, 4, 5
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3
+
+
+class ConvDesc(Structure):
+    _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("C_in", c_int), ("C_out", c_int), ("kh", c_int),
+                ("kw", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int), ("groups", c_int),
+                ("ldx", c_int64), ("ldy", c_int64)]
+
+
+P = c_void_p
+_SIGNATURES = {
+    "snws_version": (c_int, []),
+    "snws_last_error": (c_char_p, []),
+    "snws_confusion_hist": (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P]),
+    "snws_confusion_hist_argmax": (c_int, [P, c_int, P, c_int, c_int64, c_int64, c_int, P, P]),
+    "snws_ws_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
+    "snws_ws_bwd": (c_int, [P, P, c_int64, P, c_int, c_int, c_int, c_int, P]),
+    "snws_conv_pack_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "snws_conv_out_size": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "snws_conv_direct_fwd": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P]),
+    "snws_conv_direct_dgrad": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P]),
+    "snws_conv_direct_wgrad": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P]),
+    "snws_conv_mfma_tiles": (c_int, [c_int, c_int]),
+    "snws_conv_mfma_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
+    "snws_conv_mfma_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    "snws_conv_mfma_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    "snws_sn_ctx_floats": (c_int64, [c_int, c_int]),
+    "snws_sn_ctxb_floats": (c_int64, [c_int, c_int]),
+    "snws_sn_stats_tiles": (c_int, [c_int, c_int64, c_int]),
+    "snws_sn_stats": (c_int, [P, c_int, c_int, c_int64, c_int, c_int64, P, P, P]),
+    "snws_sn_finalize": (c_int, [P, c_int, P, c_int, c_int, c_int64, c_int, P, P]),
+    "snws_sn_mix_a": (c_int, [P, P, c_int, c_int, P]),
+    "snws_sn_mix_b": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P]),
+    "snws_sn_apply": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, c_int, c_int64, c_int, c_int, P]),
+    "snws_sn_bwd_reduce": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64, c_int, c_int,
+                                   P, P]),
+    "snws_sn_bwd_mix_a": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, P]),
+    "snws_sn_bwd_mix_b": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_float, c_int, c_int, P]),
+    "snws_sn_bwd_apply": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64,
+                                  c_int, c_int, P]),
+    "snws_resample_fwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "snws_resample_bwd": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  P]),
+}
+
+# entry points that return a status code (the others return a value)
+_STATUS = {k for k, (res, _) in _SIGNATURES.items() if res is c_int} - {
+    "snws_version", "snws_conv_out_size", "snws_conv_mfma_tiles", "snws_sn_stats_tiles"}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class SnwsUnsupported(NotImplementedError):
+    """The MFMA fast path does not take this shape; the caller may pick the direct kernels instead."""
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libsnws.so not found at %s - build it with __graft_entry__.build() "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Call a status-returning entry point; translate a failure into the matching Python exception."""
+    rc = getattr(lib(), name)(*args)
+    if name in _STATUS and rc != 0:
+        msg = lib().snws_last_error().decode("utf-8", "replace")
+        if rc == ERR_INVALID:
+            raise ValueError(msg)
+        if rc == ERR_UNSUPPORTED:
+            raise SnwsUnsupported(msg)
+        raise RuntimeError(msg)
+    return rc

@@ -1,0 +1,423 @@
+"""Host-side plumbing over the libsnws C ABI: tensor layout handling, kernel-path selection and the
+torch.autograd.Functions behind Conv2dws / SwitchNorm2d / the fused ConvSnRelu block.
+
+Tensors keep the reference's logical NCHW shape; physically they are NHWC ("channels last"), which is what
+the kernels read.  Everything here requires a GPU tensor: there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.SNWS_F32, torch.bfloat16: L.SNWS_BF16}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s runs on the MI355X HIP kernels only; got a %s tensor (there is no CPU fallback)"
+                           % (what, t.device))
+
+
+def dtype_code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("snws kernels take float32 or bfloat16 activations, got %s" % t.dtype)
+
+
+def as_nhwc(x):
+    """(N,C,H,W) logical tensor -> (tensor whose storage is NHWC starting at data_ptr, pixel stride ld).
+    A channels-last tensor or a channel slice of one is used in place; anything else is copied."""
+    N, C, H, W = x.shape
+    s = x.stride()
+    ld = s[3] if W > 1 else (s[2] if H > 1 else (s[0] if N > 1 else C))
+    ok = (C == 1 or s[1] == 1) and (W == 1 or s[3] == ld) and (H == 1 or s[2] == W * ld) and \
+         (N == 1 or s[0] == H * W * ld) and ld >= C
+    if ok:
+        return x, ld
+    xc = x.contiguous(memory_format=torch.channels_last)
+    if xc.stride()[1] != 1 and C > 1:  # degenerate shapes where torch keeps NCHW strides
+        xc = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return xc, C
+
+
+def new_nhwc(N, C, H, W, dtype, device):
+    """Fresh logical (N,C,H,W) tensor with NHWC storage."""
+    return torch.empty((N, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+class ConvCfg:
+    def __init__(self, weight_shape, stride, padding, dilation, groups):
+        def one(v):
+            if isinstance(v, (tuple, list)):
+                if len(set(v)) != 1:
+                    raise NotImplementedError("snws convolutions take equal stride/padding/dilation on both axes")
+                return int(v[0])
+            return int(v)
+        self.O, self.Ig, self.kh, self.kw = [int(v) for v in weight_shape]
+        self.stride, self.pad, self.dil, self.groups = one(stride), one(padding), one(dilation), int(groups)
+        if isinstance(padding, str):
+            raise NotImplementedError("string padding modes are not supported")
+        self.I = self.Ig * self.groups
+
+    def mfma_shape_ok(self):
+        k3 = self.kh == 3 and self.kw == 3 and self.pad == 1
+        k1 = self.kh == 1 and self.kw == 1 and self.pad == 0
+        return (k3 or k1) and self.stride == 1 and self.dil == 1 and self.groups == 1 and self.O % 8 == 0
+
+    def desc(self, N, H, W, c_in, ldx, ldy):
+        return L.ConvDesc(N, H, W, c_in, self.O, self.kh, self.kw, self.stride, self.pad, self.dil, self.groups,
+                          ldx, ldy)
+
+    def out_hw(self, H, W):
+        lib = L.lib()
+        return (lib.snws_conv_out_size(H, self.kh, self.stride, self.pad, self.dil),
+                lib.snws_conv_out_size(W, self.kw, self.stride, self.pad, self.dil))
+
+
+class PreparedWeight:
+    """Standardized filter in the layouts the kernels read, valid for one version of the master weight."""
+
+    def __init__(self, weight, cfg, want_mfma):
+        require_gpu(weight, "Conv2dws")
+        w = weight.detach()
+        if w.dtype != torch.float32:
+            w = w.float()
+        w = w.contiguous()
+        dev = w.device
+        self.cfg = cfg
+        self.ohwi = torch.empty((cfg.O, cfg.kh, cfg.kw, cfg.Ig), dtype=torch.float32, device=dev)
+        self.pack_fwd = self.pack_dgrad = None
+        if want_mfma:
+            nbytes = L.lib().snws_conv_pack_bytes(cfg.I, cfg.O, cfg.kh, cfg.kw)
+            self.pack_fwd = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=dev)
+            nbytes = L.lib().snws_conv_pack_bytes(cfg.O, cfg.I, cfg.kh, cfg.kw)
+            self.pack_dgrad = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=dev)
+        L.call("snws_ws_fwd", _ptr(w), cfg.O, cfg.Ig, cfg.kh, cfg.kw, None, _ptr(self.ohwi), _ptr(self.pack_fwd),
+               _ptr(self.pack_dgrad), _stream())
+
+
+def _pad_channels(x, ld, c_to):
+    """NHWC tensor with its channel count zero-padded to c_to (first-layer inputs: 14 -> 16)."""
+    N, C, H, W = x.shape
+    out = torch.zeros((N, H, W, c_to), dtype=x.dtype, device=x.device)
+    out[..., :C] = x.permute(0, 2, 3, 1)
+    return out.permute(0, 3, 1, 2), c_to
+
+
+def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
+    """y = conv(x, standardized weight) + bias.  Returns (y, stat_part or None, saved) where `saved` is what
+    conv_backward needs."""
+    cfg = prep.cfg
+    require_gpu(x, "Conv2dws")
+    N, C, H, W = x.shape
+    if C != cfg.I:
+        raise RuntimeError("Conv2dws: expected %d input channels, got %d" % (cfg.I, C))
+    dt = dtype_code(x)
+    xs, ldx = as_nhwc(x)
+    OH, OW = cfg.out_hw(H, W)
+    use_mfma = (not force_direct) and prep.pack_fwd is not None and x.dtype == torch.bfloat16 and cfg.mfma_shape_ok()
+    b32 = None if bias is None else (bias.detach() if bias.dtype == torch.float32 else bias.detach().float())
+    stat = None
+    if use_mfma:
+        c_run = (C + 15) // 16 * 16
+        if c_run != C or ldx % 8 or xs.data_ptr() % 16:
+            xs, ldx = _pad_channels(xs, ldx, c_run)
+        y = new_nhwc(N, cfg.O, OH, OW, x.dtype, x.device)
+        if want_stats:
+            T = L.lib().snws_conv_mfma_tiles(H, W)
+            stat = torch.empty((N, T, cfg.O, 2), dtype=torch.float32, device=x.device)
+        d = cfg.desc(N, H, W, c_run, ldx, cfg.O)
+        try:
+            L.call("snws_conv_mfma_fwd", ctypes.byref(d), _ptr(xs), _ptr(prep.pack_fwd), _ptr(b32), _ptr(y), _ptr(stat),
+                   _stream())
+        except L.SnwsUnsupported:
+            use_mfma, stat = False, None
+    if not use_mfma:
+        y = new_nhwc(N, cfg.O, OH, OW, x.dtype, x.device)
+        d = cfg.desc(N, H, W, C, ldx, cfg.O)
+        L.call("snws_conv_direct_fwd", ctypes.byref(d), dt, _ptr(xs), _ptr(prep.ohwi), _ptr(b32), _ptr(y), _stream())
+    saved = (xs, ldx, (N, C, H, W), use_mfma)
+    return y, stat, saved
+
+
+def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db):
+    """Returns (dx or None, dw (O,I/g,kh,kw) f32 or None, dbias f32 or None)."""
+    cfg = prep.cfg
+    xs, ldx, (N, C, H, W), used_mfma = saved
+    dys, lddy = as_nhwc(dy)
+    dt = dtype_code(dys)
+    dev = dys.device
+    c_run = xs.shape[1]
+    dx = dw = db = None
+    if need_dx:
+        done = False
+        if used_mfma and cfg.O % 16 == 0 and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
+            dxp = new_nhwc(N, c_run, H, W, dys.dtype, dev)
+            d = cfg.desc(N, H, W, c_run, c_run, lddy)
+            try:
+                L.call("snws_conv_mfma_dgrad", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), _stream())
+                dx = dxp[:, :C] if c_run != C else dxp
+                done = True
+            except L.SnwsUnsupported:
+                pass
+        if not done:
+            dx = new_nhwc(N, C, H, W, dys.dtype, dev)
+            d = cfg.desc(N, H, W, C, C, lddy)
+            L.call("snws_conv_direct_dgrad", ctypes.byref(d), dt, _ptr(dys), _ptr(prep.ohwi), _ptr(dx), _stream())
+    if need_dw or need_db:
+        done = False
+        if need_db:
+            db = torch.zeros(cfg.O, dtype=torch.float32, device=dev)
+        if used_mfma and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
+            g = torch.zeros((cfg.O, cfg.kh, cfg.kw, c_run), dtype=torch.float32, device=dev)
+            d = cfg.desc(N, H, W, c_run, ldx, lddy)
+            try:
+                L.call("snws_conv_mfma_wgrad", ctypes.byref(d), _ptr(xs), _ptr(dys), _ptr(g), _ptr(db), _stream())
+                ldg, done = c_run, True
+            except L.SnwsUnsupported:
+                pass
+        if not done:
+            g = torch.empty((cfg.O, cfg.kh, cfg.kw, cfg.Ig), dtype=torch.float32, device=dev)
+            d = cfg.desc(N, H, W, C, ldx, lddy)
+            L.call("snws_conv_direct_wgrad", ctypes.byref(d), dt, _ptr(xs), _ptr(dys), _ptr(g), _ptr(db), _stream())
+            ldg = cfg.Ig
+        if need_dw:
+            w32 = weight.detach()
+            w32 = (w32 if w32.dtype == torch.float32 else w32.float()).contiguous()
+            dw = torch.empty((cfg.O, cfg.Ig, cfg.kh, cfg.kw), dtype=torch.float32, device=dev)
+            L.call("snws_ws_bwd", _ptr(w32), _ptr(g), ldg, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------------ SwitchNorm
+def _allreduce_sum(t, group):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def sync_world(group=None):
+    """Number of data-parallel ranks whose BN-branch statistics are summed (1 when not distributed)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+class SNParams:
+    """Plain bundle of one SwitchNorm2d's tensors and flags (module attributes, modeling/snorm.py:6-25)."""
+
+    def __init__(self, mod):
+        self.gamma, self.beta = mod.weight, mod.bias
+        self.mean_weight, self.var_weight = mod.mean_weight, mod.var_weight
+        self.using_bn, self.using_movavg = bool(mod.using_bn), bool(mod.using_movavg)
+        self.running_mean = mod.running_mean if self.using_bn else None
+        self.running_var = mod.running_var if self.using_bn else None
+        self.eps, self.momentum, self.training = float(mod.eps), float(mod.momentum), bool(mod.training)
+        self.sync = bool(getattr(mod, "sync_bn_stats", True))
+        self.group = getattr(mod, "process_group", None)
+
+
+def _f32c(t):
+    t = t.detach()
+    return (t if t.dtype == torch.float32 else t.float()).contiguous()
+
+
+def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None):
+    """SwitchNorm (+ReLU) of the logical (N,C,H,W) tensor x.  stat_part/stat_shift: partial moments from the
+    conv epilogue (then x is not re-read for statistics).  Returns (y, saved)."""
+    require_gpu(x, "SwitchNorm2d")
+    N, C, H, W = x.shape
+    HW = H * W
+    dt = dtype_code(x)
+    dev = x.device
+    lib = L.lib()
+    xs, ldx = as_nhwc(x)
+    st = _stream()
+    ctx = torch.empty(lib.snws_sn_ctx_floats(N, C), dtype=torch.float32, device=dev)
+    if stat_part is None:
+        T = lib.snws_sn_stats_tiles(N, HW, C)
+        stat_part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
+        stat_shift = torch.empty((N, C), dtype=torch.float32, device=dev)
+        L.call("snws_sn_stats", _ptr(xs), dt, N, HW, C, ldx, _ptr(stat_part), _ptr(stat_shift), st)
+        per_image = 1
+    else:
+        T = stat_part.shape[1]
+        per_image = 0
+    L.call("snws_sn_finalize", _ptr(stat_part), T, _ptr(stat_shift), per_image, N, HW, C, _ptr(ctx), st)
+    pack = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
+    L.call("snws_sn_mix_a", _ptr(ctx), _ptr(pack), N, C, st)
+    world = sync_world(p.group) if (p.sync and p.training and p.using_bn) else 1
+    if world > 1:
+        _allreduce_sum(pack, p.group)
+    gamma, beta = _f32c(p.gamma).view(-1), _f32c(p.beta).view(-1)
+    mw, vw = _f32c(p.mean_weight), _f32c(p.var_weight)
+    rm = p.running_mean.view(-1) if p.using_bn else None
+    rv = p.running_var.view(-1) if p.using_bn else None
+    if p.using_bn and (rm.dtype != torch.float32 or not rm.is_contiguous() or rv.dtype != torch.float32):
+        raise TypeError("SwitchNorm2d running buffers must be contiguous float32")
+    L.call("snws_sn_mix_b", _ptr(ctx), _ptr(pack), _ptr(gamma), _ptr(mw), _ptr(vw), _ptr(rm), _ptr(rv), N, C,
+           p.eps, p.momentum, int(p.training), int(p.using_movavg), int(p.using_bn), st)
+    y = new_nhwc(N, C, H, W, x.dtype, dev)
+    rs, ldr = (None, 0)
+    if residual is not None:
+        rs, ldr = as_nhwc(residual.to(x.dtype))
+    L.call("snws_sn_apply", _ptr(xs), ldx, _ptr(y), C, _ptr(rs), ldr, dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
+    n_global = float(N * world) if world > 1 else float(N)
+    saved = dict(xs=xs, ldx=ldx, ctx=ctx, gamma=gamma, beta=beta, mw=mw, vw=vw, relu=bool(relu), shape=(N, C, H, W),
+                 training=p.training, using_bn=p.using_bn, world=world, group=p.group, n_global=n_global,
+                 y=(y if residual is not None and relu else None))
+    return y, saved
+
+
+def sn_backward(dy, s):
+    """Returns (dx, dgamma (C), dbeta (C), dmean_weight, dvar_weight); dx also is the residual branch's gradient
+    masked by the ReLU when the forward had a residual (returned as sixth value)."""
+    N, C, H, W = s["shape"]
+    HW = H * W
+    lib = L.lib()
+    st = _stream()
+    dys, lddy = as_nhwc(dy)
+    if dys.dtype != s["xs"].dtype:
+        dys, lddy = as_nhwc(dy.to(s["xs"].dtype))
+    dt = dtype_code(dys)
+    dev = dys.device
+    ym = s["y"]
+    yms, ldym = (None, 0) if ym is None else as_nhwc(ym)
+    T = lib.snws_sn_stats_tiles(N, HW, C)
+    part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
+    L.call("snws_sn_bwd_reduce", _ptr(dys), lddy, _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, dt, _ptr(s["ctx"]),
+           _ptr(s["gamma"]), _ptr(s["beta"]), N, HW, C, int(s["relu"]), _ptr(part), st)
+    ctxb = torch.empty(lib.snws_sn_ctxb_floats(N, C), dtype=torch.float32, device=dev)
+    packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    L.call("snws_sn_bwd_mix_a", _ptr(part), T, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(ctxb), _ptr(packb), _ptr(dgamma),
+           _ptr(dbeta), N, C, st)
+    if s["world"] > 1:
+        _allreduce_sum(packb, s["group"])
+    K = s["mw"].numel()
+    dmw = torch.empty(K, dtype=torch.float32, device=dev)
+    dvw = torch.empty(K, dtype=torch.float32, device=dev)
+    L.call("snws_sn_bwd_mix_b", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), _ptr(s["mw"]), _ptr(s["vw"]), None, None,
+           _ptr(dmw), _ptr(dvw), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), st)
+    dx = new_nhwc(N, C, H, W, dys.dtype, dev)
+    L.call("snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt,
+           _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C, int(s["relu"]), st)
+    return dx, dgamma, dbeta, dmw, dvw
+
+
+# ------------------------------------------------------------------------------------------------ autograd
+class Conv2dwsFn(torch.autograd.Function):
+    """Conv2dws.forward of modeling/weightstd.py:12-18 as one differentiable op."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, prep, force_direct):
+        y, _, saved = conv_forward(x, prep, bias, want_stats=False, force_direct=force_direct)
+        ctx.prep, ctx.saved, ctx.has_bias = prep, saved, bias is not None
+        ctx.save_for_backward(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb)
+        if dw is not None:
+            dw = dw.to(weight.dtype)
+        return dx, dw, db, None, None
+
+
+class SwitchNormFn(torch.autograd.Function):
+    """SwitchNorm2d.forward of modeling/snorm.py:41-81 (optionally + ReLU) as one differentiable op."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean_weight, var_weight, p, relu):
+        y, saved = sn_forward(x, p, relu)
+        ctx.s = saved
+        ctx.shapes = (gamma.shape, beta.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dg, db, dmw, dvw = sn_backward(dy, ctx.s)
+        return dx, dg.view(ctx.shapes[0]), db.view(ctx.shapes[1]), dmw, dvw, None, None
+
+
+class ConvSnReluFn(torch.autograd.Function):
+    """The ConvSnRelu block of modeling/UNet3p_SNws.py:29-33 fused: the conv epilogue hands SwitchNorm its
+    partial moments, SwitchNorm applies the ReLU, and only the conv output is kept for backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, mean_weight, var_weight, prep, p, relu):
+        conv_out, stat, saved = conv_forward(x, prep, bias, want_stats=True)
+        shift = None
+        if stat is not None:
+            shift = _f32c(bias) if bias is not None else torch.zeros(weight.shape[0], dtype=torch.float32,
+                                                                       device=x.device)
+        y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift)
+        ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
+        ctx.shapes = (gamma.shape, beta.shape)
+        ctx.save_for_backward(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn)
+        ctx.sn = None
+        nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb)
+        ctx.saved = None
+        if dw is not None:
+            dw = dw.to(weight.dtype)
+        return dx, dw, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ resampling
+_MODE = {"copy": 0, "maxpool": 1, "bilinear": 2}
+
+
+class ResampleFn(torch.autograd.Function):
+    """nn.MaxPool2d(k,k,ceil_mode=True) / nn.Upsample(k,'bilinear') of modeling/UNet3p_SNws.py:49-55."""
+
+    @staticmethod
+    def forward(ctx, x, mode, k):
+        require_gpu(x, "resample")
+        N, C, H, W = x.shape
+        xs, ld = as_nhwc(x)
+        m = _MODE[mode]
+        OH, OW = (H, W) if m == 0 else ((-(-H // k), -(-W // k)) if m == 1 else (H * k, W * k))
+        y = new_nhwc(N, C, OH, OW, x.dtype, x.device)
+        L.call("snws_resample_fwd", _ptr(xs), ld, _ptr(y), C, dtype_code(x), N, H, W, C, m, k, _stream())
+        ctx.meta = (m, k, (N, C, H, W), ld)
+        ctx.save_for_backward(xs if m == 1 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m, k, (N, C, H, W), ld = ctx.meta
+        (xs,) = ctx.saved_tensors
+        dys, ldd = as_nhwc(dy)
+        dx = torch.zeros((N, H, W, C), dtype=dys.dtype, device=dys.device).permute(0, 3, 1, 2)
+        L.call("snws_resample_bwd", _ptr(dys), ldd, _ptr(xs), ld, _ptr(dx), C, dtype_code(dys), N, H, W, C, m, k,
+               _stream())
+        return dx, None, None
+
+
+def max_pool_ceil(x, k):
+    return ResampleFn.apply(x, "maxpool", int(k))
+
+
+def upsample_bilinear(x, k):
+    return ResampleFn.apply(x, "bilinear", int(k))
