@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/sec of UNet3p_SNws (14 bands -> 10 classes, n_filters 64) at 512x512 in bf16,
+batch 16 per GPU, synthetic FY-4A-shaped tiles, data-parallel over N GPUs of one node (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad -> forward -> CE/N loss -> backward -> (bucketed gradient all-reduce) -> AdamW step with the poly
+LR, i.e. Trainer.training's inner loop.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
+line.  `roofline` is for the dominant kernel (the 3x3 MFMA implicit-GEMM kernel that runs forward and dgrad):
+algorithmic FLOPs of its launches / their HIP-event durations inside the timed region, against the dense bf16 MFMA
+peak.  `cpu_baseline` times the CPU oracle (a port of the reference's arithmetic) on rank 0's host cores on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak of MI355X
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(n_filters, size, seconds_budget=30.0):
+    """CPU oracle (oracle/snws_oracle.py) forward + loss + backward of the same model on ONE image of the bench
+    resolution (if that is estimated to exceed the budget, a square crop whose side is halved until it fits)."""
+    from oracle import snws_oracle as O
+    torch.manual_seed(1)
+    state = O.make_state("unet3p", 14, n_filters, 10)
+    for k, v in state.items():
+        if k.endswith(".0.weight") or k == "output_seg_map.weight":
+            v.copy_(torch.randn_like(v) * 0.1)
+    side = size
+    # probe at 64x64 to scale the sample so the timed run stays within the budget (cost ~ pixels)
+    img = torch.rand(1, 14, 64, 64) * 255.0
+    lab = torch.randint(0, 10, (1, 64, 64)).float()
+    t0 = time.perf_counter()
+    O.model_step("unet3p", state, img, lab)
+    probe = time.perf_counter() - t0
+    while side > 64 and probe * (side / 64.0) ** 2 > seconds_budget:
+        side //= 2
+    img = torch.rand(1, 14, side, side) * 255.0
+    lab = torch.randint(0, 10, (1, side, side)).float()
+    t0 = time.perf_counter()
+    O.model_step("unet3p", state, img, lab)
+    dt = time.perf_counter() - t0
+    frac = (side * side) / float(size * size)
+    return {"value": frac / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "CPU oracle fwd+CE+bwd of UNet3p_SNws(n_filters=%d) f32 on 1 synthetic %dx%d tile "
+                      "(=%.4g of a %dx%d image), %.1f s" % (n_filters, side, side, frac, size, size, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--filters", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    from snws import harness, ops
+    from modeling.UNet3p_SNws import UNet3p_SNws
+
+    rank, world, device = harness.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+
+    torch.manual_seed(1)
+    model = UNet3p_SNws(14, args.filters, 10, 1, 1).to(device)
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if world > 1:   # identical replicas
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    trainer = harness.Trainer(model, lr=0.002, weight_decay=5e-4, total_iters=max(1000, args.steps + args.warmup))
+    img, lab = harness.synthetic_batch(args.batch, 14, args.size, 10, device, seed=1 + rank,
+                                       dtype=model.compute_dtype)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = trainer.step(img, lab)
+    barrier()
+    ops.PROFILE = None if args.no_kernel_events else []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(img, lab)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    loss_val = float(loss)
+    if world > 1:
+        lt = loss.clone()
+        dist.all_reduce(lt)
+        loss_val = float(lt)
+
+    if rank == 0:
+        kernels = {}
+        for tag, work, e0, e1 in (prof or []):
+            k = kernels.setdefault(tag, [0, 0.0, 0.0])
+            k[0] += 1
+            k[1] += work
+            k[2] += e0.elapsed_time(e1) * 1e-3
+        fam = [v for t, v in kernels.items() if t in ("conv_mfma_fwd_k3_kc32", "conv_mfma_dgrad_k3_kc32")]
+        roofline = None
+        if fam:
+            fl, tt, cnt = sum(v[1] for v in fam), sum(v[2] for v in fam), sum(v[0] for v in fam)
+            ach = fl / tt / 1e12
+            roofline = {"bound": "mfma", "kernel": "conv_fwd_kernel<KC=32,TAPS=9> (forward + dgrad launches)",
+                        "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launches": cnt,
+                        "avg_launch_ms": tt / cnt * 1e3, "flops_per_launch": fl / cnt}
+        summary = {}
+        for tag, (cnt, work, tt) in sorted(kernels.items()):
+            if tag.startswith("conv"):
+                summary[tag] = {"launches": cnt, "ms_per_step": tt / args.steps * 1e3, "TFLOP/s": work / tt / 1e12}
+            else:
+                summary[tag] = {"launches": cnt, "ms_per_step": tt / args.steps * 1e3, "GB/s": work / tt / 1e9,
+                                "frac_of_hbm_peak": work / tt / 1e9 / HBM_PEAK_GBS}
+        out = {
+            "metric": "train images/sec (node) UNet3p_SNws 512x512", "value": args.batch * world * args.steps / elapsed,
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "UNet3p_SNws(n_channels=14, n_filters=%d, n_class=10) training step, "
+                                   "%dx%d synthetic 14-band tiles, batch %d per GPU, AdamW + poly LR, CE/N loss"
+                                   % (args.filters, args.size, args.size, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "loss": loss_val, "roofline": roofline, "kernels": summary,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.filters, args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

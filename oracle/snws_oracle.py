@@ -230,14 +230,10 @@ def sync_bn_fwd(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.
 # Resampling used by the full-scale skips
 # ----------------------------------------------------------------------------
 def maxpool_ceil(x, k):
-    """nn.MaxPool2d(k, k, ceil_mode=True) as used at UNet3p_SNws.py:49-51: out = ceil(H/k), border
-    windows clipped to the image."""
-    N, C, H, W = x.shape
-    OH, OW = -(-H // k), -(-W // k)
-    ph, pw = OH * k - H, OW * k - W
-    if ph or pw:
-        x = F.pad(x, (0, pw, 0, ph), value=float('-inf'))
-    return x.reshape(N, C, OH, k, OW, k).amax(dim=(3, 5))
+    """nn.MaxPool2d(k, k, ceil_mode=True) as used at UNet3p_SNws.py:49-51: out = ceil(H/k), border windows
+    clipped to the image; backward routes the gradient to the FIRST maximum of a window (row-major scan), which
+    is what the stock op does - so the stock CPU op is used as the primitive here."""
+    return F.max_pool2d(x, k, k, ceil_mode=True)
 
 
 def _bilinear_axis(n_in, scale, dtype):
@@ -347,18 +343,26 @@ class OracleNet:
     ('convd1_1.0.weight', 'convd1_1.1.running_mean', ...).  Parameters are torch tensors with
     requires_grad so autograd gives the gradients; buffers are updated in call order like the module."""
 
-    def __init__(self, state, using_movavg=True, using_bn=True, allreduce=None):
+    def __init__(self, state, using_movavg=True, using_bn=True, allreduce=None, act_round=None):
         self.p = state
         self.using_movavg, self.using_bn = using_movavg, using_bn
         self.training = True
         self.allreduce = allreduce
+        # act_round: optional storage dtype (torch.bfloat16) to mimic where the GPU path rounds: the standardized
+        # filter, every conv output, every SwitchNorm output and every resampled map (straight-through in backward)
+        self.act_round = act_round
+
+    def rnd(self, t):
+        if self.act_round is None:
+            return t
+        return t + (t.detach().to(self.act_round).to(t.dtype) - t.detach())
 
     def csr(self, name, x):
         """ConvSnRelu block (UNet3p_SNws.py:29-33): Sequential(0=Conv2dws, 1=SwitchNorm2d, 2=ReLU)."""
         p = self.p
         w = p[name + '.0.weight']
         pad = (w.shape[2] - 1) // 2
-        y = conv2dws_fwd(x, w, p[name + '.0.bias'], 1, pad)
+        y = self.rnd(F.conv2d(x, self.rnd(ws_standardize(w)), p[name + '.0.bias'], 1, pad))
         st = SNState.__new__(SNState)
         st.C, st.eps, st.momentum = w.shape[0], 1e-5, 0.997
         st.using_movavg, st.using_bn = self.using_movavg, self.using_bn
@@ -368,14 +372,15 @@ class OracleNet:
         st.running_mean = p[name + '.1.running_mean'].view(-1)
         st.running_var = p[name + '.1.running_var'].view(-1)
         out, _ = switchnorm_fwd(y, st, self.training, self.allreduce, relu=True)
-        return out
+        return self.rnd(out)
 
     def head(self, x):
-        return F.conv2d(x, self.p['output_seg_map.weight'], self.p['output_seg_map.bias'])
+        return self.rnd(F.conv2d(x, self.rnd(self.p['output_seg_map.weight']), self.rnd(self.p['output_seg_map.bias'])))
 
     def unet3p(self, x):
         """UNet3p_SNws.py:96-160."""
-        c, mp, up = self.csr, maxpool_ceil, upsample_bilinear
+        c, mp = self.csr, maxpool_ceil
+        up = lambda t, k: self.rnd(upsample_bilinear(t, k))  # noqa: E731
         d1 = c('convd1_2', c('convd1_1', x))
         d2 = c('convd2_2', c('convd2_1', mp(d1, 2)))
         d3 = c('convd3_2', c('convd3_1', mp(d2, 2)))
@@ -397,7 +402,8 @@ class OracleNet:
 
     def unet(self, x):
         """UNet_SNws.py:95-152."""
-        c, mp, up = self.csr, maxpool_ceil, upsample_bilinear
+        c, mp = self.csr, maxpool_ceil
+        up = lambda t, k: self.rnd(upsample_bilinear(t, k))  # noqa: E731
         c1 = c('conv1_2', c('conv1_1', x))
         c2 = c('conv2_2', c('conv2_1', mp(c1, 2)))
         c3 = c('conv3_2', c('conv3_1', mp(c2, 2)))
@@ -459,10 +465,10 @@ def is_buffer(key):
     return key.endswith('running_mean') or key.endswith('running_var')
 
 
-def model_step(arch, state, img, target, training=True, allreduce=None, loss_div=None):
+def model_step(arch, state, img, target, training=True, allreduce=None, loss_div=None, act_round=None):
     """One forward (+ backward when training) of the oracle model.  Returns logits, loss, grads dict."""
     params = {k: (v if is_buffer(k) else v.detach().clone().requires_grad_(training)) for k, v in state.items()}
-    net = OracleNet(params, allreduce=allreduce)
+    net = OracleNet(params, allreduce=allreduce, act_round=act_round)
     net.training = training
     logits = net.unet3p(img) if arch == 'unet3p' else net.unet(img)
     loss = ce_loss_batch_avg(logits, target)

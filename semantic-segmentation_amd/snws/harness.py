@@ -1,0 +1,179 @@
+"""Training / validation step harness that reproduces Trainer.training and Trainer.validation of the
+reference's train.py:237-341 for the SNws models, one process per GPU.
+
+Reference semantics kept: poly LR set every iteration (utils/lr_scheduler.py:43-70), optimizer.zero_grad ->
+forward -> CrossEntropy(mean over non-ignored pixels, ignore_index 255) / batch size (utils/loss.py:146-159)
+-> backward -> AdamW(lr 0.002, weight_decay 5e-4) step (train.py:81,384,393); validation = eval-mode forward,
+channel argmax, Evaluator.add_batch (train.py:279-304).
+
+Data parallelism replaces nn.DataParallel (train.py:212): every rank holds a replica and its own shard of the
+batch; SwitchNorm's BN branch all-reduces its per-channel sums inside forward/backward (snws.ops), the loss is
+normalised by the GLOBAL number of valid pixels and the GLOBAL batch size, and gradients are summed over ranks
+in buckets that are launched as soon as their last gradient is produced, so the all-reduces overlap the rest of
+backward.
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+def init_distributed():
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns
+    (rank, world, device).  With WORLD_SIZE unset or 1 nothing is initialised."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def poly_lr(base_lr, it, total_iters):
+    """utils/lr_scheduler.py:48 - lr = base * (1 - T/N)^0.9."""
+    return base_lr * pow((1 - 1.0 * it / total_iters), 0.9)
+
+
+def global_ce_loss(logits, target, ignore_index=255, group=None):
+    """The reference loss of the GLOBAL batch, as this rank's additive share: sum of the rank's per-pixel CE over
+    the global count of non-ignored pixels, over the global batch size.  Summed over ranks it equals
+    CrossEntropyLoss(mean)(all logits)/N_global (utils/loss.py:154-157 applied to DataParallel's gathered output,
+    train.py:250-252)."""
+    n = logits.shape[0]
+    t = target.long()
+    ce_sum = F.cross_entropy(logits.float(), t, ignore_index=ignore_index, reduction="sum")
+    cnt = torch.stack([(t != ignore_index).sum().to(torch.float32),
+                       torch.tensor(float(n), device=logits.device)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(cnt, group=group)
+    return ce_sum / cnt[0] / cnt[1]
+
+
+class GradBuckets:
+    """Sum-all-reduce of parameter gradients in ~bucket_mb buckets, overlapped with backward.
+
+    Parameters are bucketed in REVERSE registration order (the order backward tends to finish them).  A
+    post-accumulate-grad hook counts a bucket's parameters; when the last one has its final gradient (shared
+    modules fire once, after all their uses are summed) the bucket is flattened and all-reduced asynchronously.
+    finish() waits and copies the sums back.  Parameters that received no gradient (unused modules) are skipped
+    consistently on every rank because usage is data-independent."""
+
+    def __init__(self, params, bucket_mb=25.0, group=None):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []
+        cur, size = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_mb * (1 << 20):
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.where = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self.where[p] = bi
+        self.pending = [0] * len(self.buckets)
+        self.work = []
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if self.enabled:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+        self.reset()
+
+    def reset(self):
+        self.pending = [len(b) for b in self.buckets]
+        self.work = []
+
+    def _launch(self, bi):
+        ps = [p for p in self.buckets[bi] if p.grad is not None]
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
+        h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.work.append((h, flat, ps))
+
+    def _hook(self, p):
+        bi = self.where[p]
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0:
+            self._launch(bi)
+
+    def finish(self):
+        if not self.enabled:
+            return
+        for bi, left in enumerate(self.pending):     # buckets with parameters that never got a gradient
+            if left > 0:
+                self._launch(bi)
+        for h, flat, ps in self.work:
+            h.wait()
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self.reset()
+
+
+class Trainer:
+    """One-replica training driver with the reference's hyper-parameters as defaults (train.py:384-429)."""
+
+    def __init__(self, model, lr=0.002, weight_decay=5e-4, total_iters=1000, ignore_index=255, group=None,
+                 bucket_mb=25.0):
+        self.model = model
+        self.base_lr, self.total_iters, self.ignore_index, self.group = lr, total_iters, ignore_index, group
+        try:
+            self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, fused=True)
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+        self.buckets = GradBuckets(list(model.parameters()), bucket_mb, group)
+        self.it = 0
+
+    def step(self, image, target):
+        """train.py:246-255.  Returns this rank's share of the global loss (a 0-d tensor; no host sync)."""
+        lr = poly_lr(self.base_lr, self.it, self.total_iters)
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+        self.opt.zero_grad(set_to_none=True)
+        self.model.train()
+        out = self.model(image)
+        loss = global_ce_loss(out, target, self.ignore_index, self.group)
+        loss.backward()
+        self.buckets.finish()
+        self.opt.step()
+        self.it += 1
+        return loss.detach()
+
+    @torch.no_grad()
+    def validate(self, batches, evaluator):
+        """train.py:279-304 with the argmax + confusion matrix on the device."""
+        self.model.eval()
+        evaluator.reset()
+        for image, target in batches:
+            evaluator.add_batch_logits(target, self.model(image))
+        evaluator.sync(group=self.group, all_reduce=True)
+        return (evaluator.Pixel_Accuracy(), evaluator.Pixel_Accuracy_Class(),
+                evaluator.Mean_Intersection_over_Union(), evaluator.Frequency_Weighted_Intersection_over_Union())
+
+
+def synthetic_batch(batch, n_channels, size, n_class, device, seed=1, dtype=torch.float32):
+    """Synthetic FY-4A-shaped tiles: images uniform in [0,255] (the data range after the per-tile min-max x255 of
+    dataloaders/datasets/cloud_dataset.py:127-131), labels uniform integers 0..n_class-1 stored as float
+    (cloud_dataset.py:132-137)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img = torch.rand((batch, n_channels, size, size), generator=g) * 255.0
+    lab = torch.randint(0, n_class, (batch, size, size), generator=g).float()
+    return img.to(device=device, dtype=dtype), lab.to(device)

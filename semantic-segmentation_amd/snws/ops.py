@@ -13,8 +13,24 @@ from . import _lib as L
 _DT = {torch.float32: L.SNWS_F32, torch.bfloat16: L.SNWS_BF16}
 
 
+# When PROFILE is a list, every hot-path kernel launch is bracketed by two HIP events recorded on the launch
+# stream and appended as (tag, algorithmic work, start, end); bench.py reads the durations after the timed region.
+PROFILE = None
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _launch(tag, work, name, *args):
+    if PROFILE is None:
+        return L.call(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = L.call(name, *args)
+    e1.record()
+    PROFILE.append((tag, work, e0, e1))
+    return rc
 
 
 def _ptr(t):
@@ -139,8 +155,9 @@ def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
             stat = torch.empty((N, T, cfg.O, 2), dtype=torch.float32, device=x.device)
         d = cfg.desc(N, H, W, c_run, ldx, cfg.O)
         try:
-            L.call("snws_conv_mfma_fwd", ctypes.byref(d), _ptr(xs), _ptr(prep.pack_fwd), _ptr(b32), _ptr(y), _ptr(stat),
-                   _stream())
+            flops = 2.0 * N * OH * OW * cfg.O * cfg.I * cfg.kh * cfg.kw
+            _launch("conv_mfma_fwd_k%d_kc%d" % (cfg.kh, 32 if c_run % 32 == 0 else 16), flops, "snws_conv_mfma_fwd",
+                    ctypes.byref(d), _ptr(xs), _ptr(prep.pack_fwd), _ptr(b32), _ptr(y), _ptr(stat), _stream())
         except L.SnwsUnsupported:
             use_mfma, stat = False, None
     if not use_mfma:
@@ -166,7 +183,9 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db):
             dxp = new_nhwc(N, c_run, H, W, dys.dtype, dev)
             d = cfg.desc(N, H, W, c_run, c_run, lddy)
             try:
-                L.call("snws_conv_mfma_dgrad", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), _stream())
+                flops = 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw
+                _launch("conv_mfma_dgrad_k%d_kc%d" % (cfg.kh, 32 if cfg.O % 32 == 0 else 16), flops,
+                        "snws_conv_mfma_dgrad", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), _stream())
                 dx = dxp[:, :C] if c_run != C else dxp
                 done = True
             except L.SnwsUnsupported:
@@ -183,7 +202,9 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db):
             g = torch.zeros((cfg.O, cfg.kh, cfg.kw, c_run), dtype=torch.float32, device=dev)
             d = cfg.desc(N, H, W, c_run, ldx, lddy)
             try:
-                L.call("snws_conv_mfma_wgrad", ctypes.byref(d), _ptr(xs), _ptr(dys), _ptr(g), _ptr(db), _stream())
+                flops = 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw
+                _launch("conv_mfma_wgrad_k%d" % cfg.kh, flops, "snws_conv_mfma_wgrad", ctypes.byref(d), _ptr(xs),
+                        _ptr(dys), _ptr(g), _ptr(db), _stream())
                 ldg, done = c_run, True
             except L.SnwsUnsupported:
                 pass
@@ -249,7 +270,8 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None):
         T = lib.snws_sn_stats_tiles(N, HW, C)
         stat_part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
         stat_shift = torch.empty((N, C), dtype=torch.float32, device=dev)
-        L.call("snws_sn_stats", _ptr(xs), dt, N, HW, C, ldx, _ptr(stat_part), _ptr(stat_shift), st)
+        _launch("sn_stats", float(x.element_size()) * N * HW * C, "snws_sn_stats", _ptr(xs), dt, N, HW, C, ldx,
+                _ptr(stat_part), _ptr(stat_shift), st)
         per_image = 1
     else:
         T = stat_part.shape[1]
@@ -272,7 +294,8 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None):
     rs, ldr = (None, 0)
     if residual is not None:
         rs, ldr = as_nhwc(residual.to(x.dtype))
-    L.call("snws_sn_apply", _ptr(xs), ldx, _ptr(y), C, _ptr(rs), ldr, dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
+    _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), C, _ptr(rs), ldr,
+            dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
     n_global = float(N * world) if world > 1 else float(N)
     saved = dict(xs=xs, ldx=ldx, ctx=ctx, gamma=gamma, beta=beta, mw=mw, vw=vw, relu=bool(relu), shape=(N, C, H, W),
                  training=p.training, using_bn=p.using_bn, world=world, group=p.group, n_global=n_global,
@@ -296,8 +319,9 @@ def sn_backward(dy, s):
     yms, ldym = (None, 0) if ym is None else as_nhwc(ym)
     T = lib.snws_sn_stats_tiles(N, HW, C)
     part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
-    L.call("snws_sn_bwd_reduce", _ptr(dys), lddy, _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, dt, _ptr(s["ctx"]),
-           _ptr(s["gamma"]), _ptr(s["beta"]), N, HW, C, int(s["relu"]), _ptr(part), st)
+    _launch("sn_bwd_reduce", 2.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_reduce", _ptr(dys), lddy,
+            _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, dt, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(s["beta"]), N, HW, C,
+            int(s["relu"]), _ptr(part), st)
     ctxb = torch.empty(lib.snws_sn_ctxb_floats(N, C), dtype=torch.float32, device=dev)
     packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
     dgamma = torch.empty(C, dtype=torch.float32, device=dev)
@@ -312,8 +336,9 @@ def sn_backward(dy, s):
     L.call("snws_sn_bwd_mix_b", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), _ptr(s["mw"]), _ptr(s["vw"]), None, None,
            _ptr(dmw), _ptr(dvw), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), st)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
-    L.call("snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt,
-           _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C, int(s["relu"]), st)
+    _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]),
+            s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C,
+            int(s["relu"]), st)
     return dx, dgamma, dbeta, dmw, dvw
 
 
@@ -399,7 +424,8 @@ class ResampleFn(torch.autograd.Function):
         m = _MODE[mode]
         OH, OW = (H, W) if m == 0 else ((-(-H // k), -(-W // k)) if m == 1 else (H * k, W * k))
         y = new_nhwc(N, C, OH, OW, x.dtype, x.device)
-        L.call("snws_resample_fwd", _ptr(xs), ld, _ptr(y), C, dtype_code(x), N, H, W, C, m, k, _stream())
+        _launch("resample_fwd", float(x.element_size()) * N * C * (H * W + OH * OW), "snws_resample_fwd", _ptr(xs), ld,
+                _ptr(y), C, dtype_code(x), N, H, W, C, m, k, _stream())
         ctx.meta = (m, k, (N, C, H, W), ld)
         ctx.save_for_backward(xs if m == 1 else None)
         return y
@@ -410,8 +436,9 @@ class ResampleFn(torch.autograd.Function):
         (xs,) = ctx.saved_tensors
         dys, ldd = as_nhwc(dy)
         dx = torch.zeros((N, H, W, C), dtype=dys.dtype, device=dys.device).permute(0, 3, 1, 2)
-        L.call("snws_resample_bwd", _ptr(dys), ldd, _ptr(xs), ld, _ptr(dx), C, dtype_code(dys), N, H, W, C, m, k,
-               _stream())
+        OH, OW = dy.shape[2], dy.shape[3]
+        _launch("resample_bwd", float(dys.element_size()) * N * C * (H * W + OH * OW), "snws_resample_bwd", _ptr(dys),
+                ldd, _ptr(xs), ld, _ptr(dx), C, dtype_code(dys), N, H, W, C, m, k, _stream())
         return dx, None, None
 
 
