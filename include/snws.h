@@ -58,6 +58,11 @@ int snws_confusion_hist_argmax(const void* gt, int gt_dtype, const void* logits,
 int snws_ws_fwd(const float* w, int O, int I, int kh, int kw, float* what_oihw, float* what_ohwi, void* pack_fwd,
                 void* pack_dgrad, void* stream);
 
+/* The same layouts for a filter used as is (no standardisation) - the plain nn.Conv2d classification head,
+ * modeling/UNet3p_SNws.py:93. */
+int snws_conv_pack(const float* w, int O, int I, int kh, int kw, float* w_ohwi, void* pack_fwd, void* pack_dgrad,
+                   void* stream);
+
 /* dw (O,I,kh,kw) f32 = gradient w.r.t. the master weight given g = dL/d(what) stored as (O, kh, kw, ldg)
  * with ldg >= I (the wgrad kernels' output layout). */
 int snws_ws_bwd(const float* w, const float* g_ohwi, int64_t ldg, float* dw, int O, int I, int kh, int kw,
@@ -87,7 +92,8 @@ int snws_conv_direct_wgrad(const snws_conv_desc* d, int dtype, const void* x, co
                            float* dbias, void* stream);
 
 /* MFMA implicit-GEMM kernels: bf16 NHWC, f32 accumulate, kernel 3x3 (pad 1) or 1x1 (pad 0), stride 1,
- * dilation 1, groups 1, C_in a multiple of 16, C_out a multiple of 8.  Returns SNWS_ERR_UNSUPPORTED otherwise.
+ * dilation 1, groups 1, C_in a multiple of 16, C_out a multiple of 8 (dgrad: C_out a multiple of 16).
+ * Returns SNWS_ERR_UNSUPPORTED otherwise.
  *   fwd:   y = conv(x, pack_fwd) + bias.  When stat_part != NULL it also emits per-tile partial moments
  *          of the ROUNDED output for SwitchNorm: stat_part[((n*T + t)*C_out + c)*2 + {0,1}] = sum and sum of
  *          squares of (y - bias[c]) over tile t's valid pixels, T = snws_conv_mfma_tiles(H, W).

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       const int pix = i * 8 + (lane >> 3);
       const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
       const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
-      const bool ok = gy < a.H && gx < a.W;
+      const bool ok = gy < a.H && gx < a.W && cot * 64 + chunk * 8 < a.Cout;
       const void* s = ok ? (const void*)(a.dy + (((int64_t)n * a.H + gy) * a.W + gx) * a.lddy + cot * 64 + chunk * 8)
                          : (const void*)snws_zero_page;
       glds16(s, dy_lds + i * 1024);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         const int gy = y0 - G::PADK + py, gx = x0 - G::PADK + px;
         const int cl = lane % G::XVPP;
         const int chunk = CIC == 64 ? (cl ^ (((pix >> 1) & 1) << 2)) : cl;
-        const bool ok = pix < G::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const bool ok = pix < G::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cit * CIC + chunk * 8 < a.Cin;
         const void* s = ok ? (const void*)(a.x + (((int64_t)n * a.H + gy) * a.W + gx) * a.ldx + cit * CIC + chunk * 8)
                            : (const void*)snws_zero_page;
         glds16(s, x_lds + i * 1024);
@@ -529,14 +529,13 @@ extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, cons
   if (int rc = check_mfma_desc(d, "snws_conv_mfma_wgrad")) return rc;
   SNWS_CHECK_ARG(x && dy && dw_ohwi, "snws_conv_mfma_wgrad: NULL pointer");
   SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "snws_conv_mfma_wgrad: pointers must be 16-byte aligned");
-  const bool c64 = d->C_in % 64 == 0, c16 = d->C_in == 16;
-  if (!(c64 || c16) || d->C_out % 64)
-    SNWS_UNSUPPORTED("snws_conv_mfma_wgrad: C_in %d must be 16 or a multiple of 64 and C_out %d a multiple of 64", d->C_in, d->C_out);
+  // C_in == 16 takes the narrow variant; any other multiple of 16 the 64-wide one (channel tails read the zero page)
+  const bool c16 = d->C_in == 16, c64 = !c16;
   WgradArgs a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw_ohwi; a.dbias = dbias;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->C_in; a.Cout = d->C_out; a.ldx = d->ldx; a.lddy = d->ldy;
   a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
-  a.coTiles = d->C_out / 64; a.ciTiles = c64 ? d->C_in / 64 : 1;
+  a.coTiles = cdiv(d->C_out, 64); a.ciTiles = c64 ? cdiv(d->C_in, 64) : 1;
   const int ntiles = d->N * a.tilesX * a.tilesY, npairs = a.coTiles * a.ciTiles;
   int splits = cdiv(2048, npairs);
   if (splits > ntiles) splits = ntiles;

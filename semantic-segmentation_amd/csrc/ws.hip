@@ -12,6 +12,7 @@ namespace {
 constexpr int WS_THREADS = 256;
 constexpr int WS_MAX_PER_THREAD = 64;  // fan-in up to 16384
 
+template <bool STANDARDIZE>
 __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restrict__ w, int O, int I, int kh, int kw,
                                                             float* __restrict__ what_oihw,
                                                             float* __restrict__ what_ohwi, bf16_t* __restrict__ pk_fwd,
@@ -28,22 +29,25 @@ __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restr
     v[k] = i < n ? wo[i] : 0.f;
     s += v[k];
   }
-  const float mu = (float)(block_sum(s, scratch) / n);
-  double ss = 0;
+  float sd = 1.f;
+  if (STANDARDIZE) {
+    const float mu = (float)(block_sum(s, scratch) / n);
+    double ss = 0;
 #pragma unroll
-  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
-    const int i = threadIdx.x + k * WS_THREADS;
-    v[k] = i < n ? v[k] - mu : 0.f;
-    ss += (double)v[k] * v[k];
+    for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+      const int i = threadIdx.x + k * WS_THREADS;
+      v[k] = i < n ? v[k] - mu : 0.f;
+      ss += (double)v[k] * v[k];
+    }
+    sd = (float)sqrt(block_sum(ss, scratch) / (n - 1)) + 1e-5f;
   }
-  const float sd = (float)sqrt(block_sum(ss, scratch) / (n - 1)) + 1e-5f;
   const PackGeom gf = pack_geom(I, O, taps);   // forward image: contraction over input channels
   const PackGeom gd = pack_geom(O, I, taps);   // dgrad image: contraction over output channels
 #pragma unroll
   for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
     if (i >= n) break;
-    const float h = v[k] / sd;
+    const float h = STANDARDIZE ? v[k] / sd : v[k];
     const int ci = i / taps, tap = i % taps;
     if (what_oihw) what_oihw[(int64_t)o * n + i] = h;
     if (what_ohwi) what_ohwi[((int64_t)o * taps + tap) * I + ci] = h;
@@ -118,9 +122,21 @@ extern "C" int snws_ws_fwd(const float* w, int O, int I, int kh, int kw, float* 
   const int64_t n = (int64_t)I * kh * kw;
   SNWS_CHECK_ARG(n >= 2, "snws_ws_fwd: fan-in %lld < 2 has no unbiased std", (long long)n);
   if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_ws_fwd: fan-in %lld > %d", (long long)n, WS_THREADS * WS_MAX_PER_THREAD);
-  ws_fwd_kernel<<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, O, I, kh, kw, what_oihw, what_ohwi, (bf16_t*)pack_fwd,
-                                                         (bf16_t*)pack_dgrad);
+  ws_fwd_kernel<true><<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, O, I, kh, kw, what_oihw, what_ohwi,
+                                                               (bf16_t*)pack_fwd, (bf16_t*)pack_dgrad);
   SNWS_LAUNCH_CHECK("snws_ws_fwd");
+  return SNWS_OK;
+}
+
+extern "C" int snws_conv_pack(const float* w, int O, int I, int kh, int kw, float* w_ohwi, void* pack_fwd,
+                              void* pack_dgrad, void* stream) {
+  SNWS_CHECK_ARG(w, "snws_conv_pack: w is NULL");
+  SNWS_CHECK_ARG(O >= 1 && I >= 1 && kh >= 1 && kw >= 1, "snws_conv_pack: bad shape (%d,%d,%d,%d)", O, I, kh, kw);
+  const int64_t n = (int64_t)I * kh * kw;
+  if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_conv_pack: fan-in %lld > %d", (long long)n, WS_THREADS * WS_MAX_PER_THREAD);
+  ws_fwd_kernel<false><<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, O, I, kh, kw, nullptr, w_ohwi, (bf16_t*)pack_fwd,
+                                                                (bf16_t*)pack_dgrad);
+  SNWS_LAUNCH_CHECK("snws_conv_pack");
   return SNWS_OK;
 }
 

@@ -53,10 +53,18 @@ def to_device_layout(x, dtype=None):
 
 
 def head_conv(conv, x):
-    """The plain nn.Conv2d classification head (modeling/UNet3p_SNws.py:93,158) on a compute-dtype activation:
-    run in the activation's dtype (bf16 GEMM on the matrix cores), return float32 logits."""
-    if x.dtype == conv.weight.dtype:
-        return torch.nn.functional.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding)
-    w = conv.weight.to(x.dtype)
-    b = None if conv.bias is None else conv.bias.to(x.dtype)
-    return torch.nn.functional.conv2d(x, w, b, conv.stride, conv.padding).float()
+    """The plain nn.Conv2d 1x1 classification head (modeling/UNet3p_SNws.py:93,158) through the library's own conv
+    kernels; returns float32 logits.  For bf16 activations the filter is zero-padded to a multiple of 16 output
+    channels so the MFMA kernels take it; the padding is sliced off again (autograd sees plain pad/slice ops)."""
+    ops.require_gpu(x, "classification head")
+    w, b = conv.weight, conv.bias
+    n_out = w.shape[0]
+    if conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or \
+            tuple(conv.padding) != ((w.shape[2] - 1) // 2, (w.shape[3] - 1) // 2):
+        raise NotImplementedError("head_conv handles stride-1 'same' convolutions")
+    pad = (-n_out) % 16 if x.dtype == torch.bfloat16 else 0
+    if pad:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, pad))
+        b = None if b is None else torch.nn.functional.pad(b, (0, pad))
+    y = ops.PlainConvFn.apply(x, w, b)
+    return y[:, :n_out].float()

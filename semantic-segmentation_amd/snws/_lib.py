@@ -28,6 +28,7 @@ _SIGNATURES = {
     "snws_confusion_hist": (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P]),
     "snws_confusion_hist_argmax": (c_int, [P, c_int, P, c_int, c_int64, c_int64, c_int, P, P]),
     "snws_ws_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
+    "snws_conv_pack": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P]),
     "snws_ws_bwd": (c_int, [P, P, c_int64, P, c_int, c_int, c_int, c_int, P]),
     "snws_conv_pack_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "snws_conv_out_size": (c_int, [c_int, c_int, c_int, c_int, c_int]),

@@ -104,8 +104,9 @@ class ConvCfg:
 class PreparedWeight:
     """Standardized filter in the layouts the kernels read, valid for one version of the master weight."""
 
-    def __init__(self, weight, cfg, want_mfma):
+    def __init__(self, weight, cfg, want_mfma, standardize=True):
         require_gpu(weight, "Conv2dws")
+        self.standardize = standardize
         w = weight.detach()
         if w.dtype != torch.float32:
             w = w.float()
@@ -119,8 +120,12 @@ class PreparedWeight:
             self.pack_fwd = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=dev)
             nbytes = L.lib().snws_conv_pack_bytes(cfg.O, cfg.I, cfg.kh, cfg.kw)
             self.pack_dgrad = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=dev)
-        L.call("snws_ws_fwd", _ptr(w), cfg.O, cfg.Ig, cfg.kh, cfg.kw, None, _ptr(self.ohwi), _ptr(self.pack_fwd),
-               _ptr(self.pack_dgrad), _stream())
+        if standardize:
+            L.call("snws_ws_fwd", _ptr(w), cfg.O, cfg.Ig, cfg.kh, cfg.kw, None, _ptr(self.ohwi), _ptr(self.pack_fwd),
+                   _ptr(self.pack_dgrad), _stream())
+        else:
+            L.call("snws_conv_pack", _ptr(w), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _ptr(self.ohwi), _ptr(self.pack_fwd),
+                   _ptr(self.pack_dgrad), _stream())
 
 
 def _pad_channels(x, ld, c_to):
@@ -213,7 +218,9 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db):
             d = cfg.desc(N, H, W, C, ldx, lddy)
             L.call("snws_conv_direct_wgrad", ctypes.byref(d), dt, _ptr(xs), _ptr(dys), _ptr(g), _ptr(db), _stream())
             ldg = cfg.Ig
-        if need_dw:
+        if need_dw and not prep.standardize:
+            dw = g[..., :cfg.Ig].permute(0, 3, 1, 2).contiguous()
+        elif need_dw:
             w32 = weight.detach()
             w32 = (w32 if w32.dtype == torch.float32 else w32.float()).contiguous()
             dw = torch.empty((cfg.O, cfg.Ig, cfg.kh, cfg.kw), dtype=torch.float32, device=dev)
@@ -361,6 +368,28 @@ class Conv2dwsFn(torch.autograd.Function):
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db, None, None
+
+
+class PlainConvFn(torch.autograd.Function):
+    """A plain (not standardized) convolution through the same kernels - the nn.Conv2d classification head."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        cfg = ConvCfg(weight.shape, 1, (weight.shape[2] - 1) // 2, 1, 1)
+        prep = PreparedWeight(weight, cfg, x.dtype == torch.bfloat16, standardize=False)
+        y, _, saved = conv_forward(x, prep, bias)
+        ctx.prep, ctx.saved, ctx.has_bias = prep, saved, bias is not None
+        ctx.save_for_backward(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb)
+        if dw is not None:
+            dw = dw.to(weight.dtype)
+        return dx, dw, db
 
 
 class SwitchNormFn(torch.autograd.Function):

@@ -190,9 +190,9 @@ def gen_models():
 
 
 # --------------------------------------------------------------------------- G5
-def gen_loss_curve():
+def gen_loss_curve(n_filters=4, name="g5_loss_curve"):
     steps = 200
-    model = UNet3p_SNws(14, 4, 10, 1, 1)
+    model = UNet3p_SNws(14, n_filters, 10, 1, 1)
     det_init(model)
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=5e-4)
@@ -215,7 +215,7 @@ def gen_loss_curve():
             print("step", i, "loss", losses[-1], flush=True)
     rm = torch.cat([b.flatten() for n, b in model.named_buffers() if n.endswith("running_mean")])
     rv = torch.cat([b.flatten() for n, b in model.named_buffers() if n.endswith("running_var")])
-    save("g5_loss_curve", losses=np.array(losses, np.float64), lrs=np.array(lrs, np.float64),
+    save(name, losses=np.array(losses, np.float64), lrs=np.array(lrs, np.float64),
          running_mean_sum=np.array(rm.double().sum().item()), running_var_sum=np.array(rv.double().sum().item()))
 
 
@@ -322,6 +322,8 @@ if __name__ == "__main__":
         gen_models()
     if "g5" in which:
         gen_loss_curve()
+    if "g5b" in which:      # MFMA-aligned widths (16..256 channels) for the bf16 tier's 200-step curve
+        gen_loss_curve(16, "g5b_loss_curve_nf16")
     if "g6" in which:
         gen_evaluator()
     if "g78" in which:
