@@ -156,11 +156,13 @@ int snws_sn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx,
 int snws_sn_bwd_mix_a(const float* part, int T, const float* ctx, const float* gamma, float* ctxb, float* packb,
                       float* dgamma, float* dbeta, int N, int C, void* stream);
 /* After the caller's all-reduce of packb: coefficients A,B,K of dx = A*dy' + B*x + K into ctxb, and the
- * gradients of mean_weight / var_weight (overwritten, 3 or 2 entries).  n_global = global batch size. */
+ * gradients of mean_weight / var_weight (overwritten, 3 or 2 entries).  n_global = global batch size.
+ * dx_sum (nullable, C floats, overwritten): sum of dx over (n, pixels) per channel in closed form - the gradient
+ * of a per-channel bias added before the normalisation (the conv bias of a ConvSnRelu block). */
 int snws_sn_bwd_mix_b(const float* ctx, float* ctxb, const float* packb, const float* mean_weight,
                       const float* var_weight, const float* running_mean, const float* running_var,
-                      float* dmean_weight, float* dvar_weight, int N, int64_t HW, int C, float n_global,
-                      int training, int using_bn, void* stream);
+                      float* dmean_weight, float* dvar_weight, float* dx_sum, int N, int64_t HW, int C,
+                      float n_global, int training, int using_bn, void* stream);
 /* Pass 2: dx = A*dy' + B*x + K. */
 int snws_sn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask, int64_t ldy,
                       void* dx, int64_t lddx, int dtype, const float* ctx, const float* ctxb, const float* beta,
@@ -177,6 +179,22 @@ int snws_resample_fwd(const void* src, int64_t lds, void* dst, int64_t ldd, int 
                       int mode, int k, void* stream);
 int snws_resample_bwd(const void* ddst, int64_t ldd, const void* src, int64_t lds, void* dsrc, int64_t ldds,
                       int dtype, int N, int H, int W, int C, int mode, int k, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution of a bilinearly up-sampled map without materialising it - replaces the pairs
+ * Conv2dws(nn.Upsample(scale k, bilinear)(x)) of modeling/UNet3p_SNws.py:131,138-139,145-147,152-155 (and the 1x1
+ * conv after nn.Upsample of modeling/UNet_SNws.py:122-123).  The channel contraction commutes with the
+ * interpolation:  conv(up_k(x))(p) = b + sum_t [p+t inside] * up_k(Z_t)(p+t),  Z_t = W_t x.
+ *   Z  (N, h, w, ldz): ksize*ksize*C_out channels at the SOURCE resolution, tap-major (channel t*C_out + o),
+ *      produced by a 1x1 convolution (snws_conv_mfma_fwd / snws_conv_direct_fwd) with the filter re-laid as
+ *      (ksize*ksize*C_out, C_in, 1, 1).
+ *   fwd: y (N, h*k, w*k, ldy) = bias + sum over taps of the bilinear interpolation of Z_t at p+t (zero outside).
+ *   bwd: dZ (N, h, w, lddz) overwritten with the adjoint applied to dy (a gather; no atomics).
+ * ksize 1 or 3; dtype of Z, y, dy, dZ: SNWS_F32 or SNWS_BF16 (f32 accumulation). */
+int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, int dtype, int N, int h,
+                    int w, int C_out, int k, int ksize, void* stream);
+int snws_upconv_bwd(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dtype, int N, int h, int w, int C_out,
+                    int k, int ksize, void* stream);
 
 #ifdef __cplusplus
 }

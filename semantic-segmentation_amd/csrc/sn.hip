@@ -492,8 +492,9 @@ __global__ __launch_bounds__(256) void sn_bwd_mix_a2_kernel(float* __restrict__ 
 __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restrict__ ctx, float* __restrict__ ctxb,
                                                             const float* __restrict__ packb,
                                                             const float* __restrict__ mw, const float* __restrict__ vw,
-                                                            float* __restrict__ dmw, float* __restrict__ dvw, int N,
-                                                            int64_t HW, int C, float Ng, int training, int using_bn) {
+                                                            float* __restrict__ dmw, float* __restrict__ dvw,
+                                                            float* __restrict__ dxsum, int N, int64_t HW, int C,
+                                                            float Ng, int training, int using_bn) {
   __shared__ double scratch[16];
   const CtxOff o = ctx_off(N, C);
   const CtxbOff ob = ctxb_off(N, C);
@@ -533,10 +534,20 @@ __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restr
     const float B = 2.f * dvar_in / (float)(HW - 1);
     ctxb[ob.B + i] = B;
     ctxb[ob.K + i] = dmean_in / (float)HW - B * mean_in;
+    // sum over the plane of dx = A*dy' + B*x + K is A*P + dmean_in; parked in the (now consumed) dm slot
+    ctxb[ob.dm + i] = ctx[o.scale + i] * ctxb[ob.P + i] + dmean_in;
   }
   for (int k = 0; k < 3; ++k) {
     da[k] = block_sum(da[k], scratch);
     db[k] = block_sum(db[k], scratch);
+  }
+  if (dxsum) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 1024) {
+      double s = 0;
+      for (int n = 0; n < N; ++n) s += (double)ctxb[ob.dm + (int64_t)n * C + c];
+      dxsum[c] = (float)s;
+    }
   }
   if (threadIdx.x == 0) {
     double sa = 0, sb = 0;
@@ -809,15 +820,15 @@ extern "C" int snws_sn_bwd_mix_a(const float* part, int T, const float* ctx, con
 
 extern "C" int snws_sn_bwd_mix_b(const float* ctx, float* ctxb, const float* packb, const float* mean_weight,
                                  const float* var_weight, const float* running_mean, const float* running_var,
-                                 float* dmean_weight, float* dvar_weight, int N, int64_t HW, int C, float n_global,
-                                 int training, int using_bn, void* stream) {
+                                 float* dmean_weight, float* dvar_weight, float* dx_sum, int N, int64_t HW, int C,
+                                 float n_global, int training, int using_bn, void* stream) {
   (void)running_mean;
   (void)running_var;
   SNWS_CHECK_ARG(ctx && ctxb && packb && mean_weight && var_weight && dmean_weight && dvar_weight,
                  "snws_sn_bwd_mix_b: NULL pointer");
   SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1 && n_global >= 1.f, "snws_sn_bwd_mix_b: bad sizes");
   sn_bwd_mix_b_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ctx, ctxb, packb, mean_weight, var_weight, dmean_weight,
-                                                         dvar_weight, N, HW, C, n_global, training, using_bn);
+                                                         dvar_weight, dx_sum, N, HW, C, n_global, training, using_bn);
   SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_b");
   return SNWS_OK;
 }

@@ -32,15 +32,6 @@ class UNet3p_SNws(nn.Module):
         self.output_seg_map = nn.Conv2d(5 * f, n_class, kernel_size=1, stride=1, padding=0)
         self.compute_dtype = None      # None: keep the input's dtype; torch.bfloat16 for the MFMA tier
 
-    @staticmethod
-    def _to_scale(t, t_level, level):
-        """Bring encoder/decoder map `t` living at pyramid level t_level (1 = full resolution) to `level`."""
-        if t_level == level:
-            return t
-        if t_level < level:
-            return ops.max_pool_ceil(t, 2 ** (level - t_level))
-        return ops.upsample_bilinear(t, 2 ** (t_level - level))
-
     def forward(self, x):
         x = to_device_layout(x, self.compute_dtype)
         enc = {}
@@ -51,15 +42,23 @@ class UNet3p_SNws(nn.Module):
             t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
             enc[lvl] = t
         enc_cat = {1: self.convd1_cat, 2: self.convd2_cat, 3: self.convd3_cat, 4: self.convd4_cat}
+        # Every up-sampled source goes through conv(upsample(x)) = sum_t up(W_t x): the 1x1 half Z = W_taps x is
+        # computed once per source at ITS resolution and shared by all the scales that consume it.
+        z5 = self.conv5_cat.taps(enc[5])
+        zdec = {}
         dec = {}
         for level in (4, 3, 2, 1):
             parts = []
             for src in (1, 2, 3, 4):
-                if src <= level:        # encoder map, pooled down (or taken as is) to this level
-                    parts.append(enc_cat[src](self._to_scale(enc[src], src, level)))
+                if src < level:         # encoder map, max-pooled down to this level
+                    parts.append(enc_cat[src](ops.max_pool_ceil(enc[src], 2 ** (level - src))))
+                elif src == level:
+                    parts.append(enc_cat[src](enc[src]))
                 else:                   # decoder map of a coarser level, up-sampled
-                    parts.append(self.convu_cat(self._to_scale(dec[src], src, level)))
+                    if src not in zdec:
+                        zdec[src] = self.convu_cat.taps(dec[src])
+                    parts.append(self.convu_cat.up(zdec[src], 2 ** (src - level)))
             # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
-            parts.append(self.conv5_cat(self._to_scale(enc[5], 5, level)))
+            parts.append(self.conv5_cat.up(z5, 2 ** (5 - level)))
             dec[level] = self.conv_fusion(torch.cat(parts, 1))
         return head_conv(self.output_seg_map, dec[1])

@@ -39,6 +39,6 @@ class UNet_SNws(nn.Module):
         x = self.conv_d2(self.conv_d1(x))
         for (up1, c2, c3) in ((self.conv_u1, self.conv_u2, self.conv_u3), (self.conv5_1, self.conv5_2, self.conv5_3),
                               (self.conv6_1, self.conv6_2, self.conv6_3), (self.conv7_1, self.conv7_2, self.conv7_3)):
-            x = up1(ops.upsample_bilinear(x, 2))
+            x = up1.on_upsampled(x, 2)       # 1x1 conv of the x2 up-sampled map, computed at low resolution
             x = c3(c2(crop_concat(skips.pop(), x)))
         return head_conv(self.output_seg_map, x)

@@ -35,6 +35,24 @@ class ConvSnRelu(nn.Sequential):
                                       norm.var_weight, prep, ops.SNParams(norm), True)
 
 
+    # ---- the block applied to nn.Upsample(scale_factor=k, mode='bilinear')(x), without building the up-sampled map
+    def taps(self, x):
+        """Z = W_taps x at x's resolution; feed it to up(Z, k) for every scale k that needs conv(upsample_k(x))."""
+        conv = self[0]
+        ops.require_gpu(x, "ConvSnRelu")
+        tp = conv.prepared_taps(x.dtype == torch.bfloat16 and not conv.force_direct)
+        return ops.TapConvFn.apply(x, conv.weight, tp)
+
+    def up(self, z, k):
+        conv, norm = self[0], self[1]
+        return ops.UpTapSnReluFn.apply(z, conv.bias, norm.weight, norm.bias, norm.mean_weight, norm.var_weight,
+                                       ops.SNParams(norm), int(k), conv.kernel_size[0], conv.out_channels, True)
+
+    def on_upsampled(self, x, k):
+        """== self(nn.Upsample(scale_factor=k, mode='bilinear', align_corners=False)(x))."""
+        return self.up(self.taps(x), k)
+
+
 def crop_concat(a, b):
     """Centre-crop skip `a` to b's spatial size (diff//2 from the top/left) and stack (a, b) on the channel axis
     (CropConcat, modeling/UNet_SNws.py:35-39)."""

@@ -17,6 +17,8 @@ class Conv2dws(nn.Conv2d):
         super(Conv2dws, self).__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
         self._prep = None
         self._prep_key = None
+        self._taps = None
+        self._taps_key = None
         self.force_direct = False   # True pins the exact direct kernels (float32 tier / debugging)
 
     def prepared(self, want_mfma):
@@ -30,6 +32,20 @@ class Conv2dws(nn.Conv2d):
             self._prep = ops.PreparedWeight(w, cfg, want_mfma)
             self._prep_key = key
         return self._prep
+
+    def prepared_taps(self, want_mfma):
+        """The standardized filter re-laid as a (kh*kw*O, I, 1, 1) filter for conv-of-an-up-sampled-map
+        (snws.ops.TapConvFn); cached per weight version like prepared()."""
+        w = self.weight
+        key = (w._version, w.data_ptr(), w.device, bool(want_mfma))
+        if self._taps is None or self._taps_key != key:
+            cfg = ops.ConvCfg(w.shape, self.stride, self.padding, self.dilation, self.groups)
+            if cfg.stride != 1 or cfg.dil != 1 or cfg.groups != 1 or cfg.kh != cfg.kw or cfg.kh not in (1, 3) or \
+                    cfg.pad != (cfg.kh - 1) // 2:
+                raise NotImplementedError("conv-of-upsample needs a stride-1 'same' 1x1 or 3x3 convolution")
+            self._taps = ops.PreparedTaps(w, cfg, want_mfma)
+            self._taps_key = key
+        return self._taps
 
     def forward(self, x):
         if x.dim() != 4:

@@ -50,9 +50,11 @@ _SIGNATURES = {
     "snws_sn_bwd_reduce": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64, c_int, c_int,
                                    P, P]),
     "snws_sn_bwd_mix_a": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, P]),
-    "snws_sn_bwd_mix_b": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_float, c_int, c_int, P]),
+    "snws_sn_bwd_mix_b": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_float, c_int, c_int, P]),
     "snws_sn_bwd_apply": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64,
                                   c_int, c_int, P]),
+    "snws_upconv_fwd": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "snws_upconv_bwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_resample_fwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_resample_bwd": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   P]),

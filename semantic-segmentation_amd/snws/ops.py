@@ -310,9 +310,9 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None):
     return y, saved
 
 
-def sn_backward(dy, s):
-    """Returns (dx, dgamma (C), dbeta (C), dmean_weight, dvar_weight); dx also is the residual branch's gradient
-    masked by the ReLU when the forward had a residual (returned as sixth value)."""
+def sn_backward(dy, s, want_dx_sum=False):
+    """Returns (dx, dgamma (C), dbeta (C), dmean_weight, dvar_weight[, dx_sum (C)]).  dx_sum is the closed-form
+    per-channel sum of dx, i.e. the gradient of a bias added just before the normalisation."""
     N, C, H, W = s["shape"]
     HW = H * W
     lib = L.lib()
@@ -340,12 +340,15 @@ def sn_backward(dy, s):
     K = s["mw"].numel()
     dmw = torch.empty(K, dtype=torch.float32, device=dev)
     dvw = torch.empty(K, dtype=torch.float32, device=dev)
+    dxsum = torch.empty(C, dtype=torch.float32, device=dev) if want_dx_sum else None
     L.call("snws_sn_bwd_mix_b", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), _ptr(s["mw"]), _ptr(s["vw"]), None, None,
-           _ptr(dmw), _ptr(dvw), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), st)
+           _ptr(dmw), _ptr(dvw), _ptr(dxsum), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), st)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
     _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]),
             s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C,
             int(s["relu"]), st)
+    if want_dx_sum:
+        return dx, dgamma, dbeta, dmw, dvw, dxsum
     return dx, dgamma, dbeta, dmw, dvw
 
 
@@ -436,6 +439,83 @@ class ConvSnReluFn(torch.autograd.Function):
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ conv of an up-sampled map
+class PreparedTaps:
+    """The standardized filter of a Conv2dws re-laid as a 1x1 filter with taps*O output channels (tap-major):
+    Z = W_taps x at the SOURCE resolution is all the matrix work conv(upsample(x)) needs."""
+
+    def __init__(self, weight, cfg, want_mfma):
+        require_gpu(weight, "Conv2dws")
+        w = _f32c(weight)
+        what = torch.empty_like(w)
+        L.call("snws_ws_fwd", _ptr(w), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _ptr(what), None, None, None, _stream())
+        wre = what.permute(2, 3, 0, 1).reshape(cfg.kh * cfg.kw * cfg.O, cfg.Ig, 1, 1).contiguous()
+        self.cfg = cfg
+        self.cfg_re = ConvCfg(wre.shape, 1, 0, 1, 1)
+        self.prep = PreparedWeight(wre, self.cfg_re, want_mfma, standardize=False)
+
+
+class TapConvFn(torch.autograd.Function):
+    """x (N,I,h,w) -> Z (N, taps*O, h, w): the 1x1 half of conv(upsample(x)).  Backward receives the sum of dZ over
+    every scale that used Z and runs dgrad / wgrad / the standardisation backward once."""
+
+    @staticmethod
+    def forward(ctx, x, weight, taps_prep):
+        z, _, saved = conv_forward(x, taps_prep.prep, None)
+        ctx.tp, ctx.saved = taps_prep, saved
+        ctx.save_for_backward(weight)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (weight,) = ctx.saved_tensors
+        tp = ctx.tp
+        cfg = tp.cfg
+        dx, dwre, _ = conv_backward(dz, tp.prep, ctx.saved, None, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                    False)
+        dw = None
+        if dwre is not None:
+            g = dwre.view(cfg.kh, cfg.kw, cfg.O, cfg.Ig).permute(2, 0, 1, 3).contiguous()
+            w32 = _f32c(weight)
+            dw = torch.empty((cfg.O, cfg.Ig, cfg.kh, cfg.kw), dtype=torch.float32, device=g.device)
+            L.call("snws_ws_bwd", _ptr(w32), _ptr(g), cfg.Ig, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
+            dw = dw.to(weight.dtype)
+        ctx.saved = None
+        return dx, dw, None
+
+
+class UpTapSnReluFn(torch.autograd.Function):
+    """Z -> SwitchNorm(ReLU)(bias + sum_t up_k(Z_t) shifted by t): the memory-bound half of
+    ConvSnRelu(nn.Upsample(k)(x)), modeling/UNet3p_SNws.py:131-155, with the block's SwitchNorm + ReLU."""
+
+    @staticmethod
+    def forward(ctx, z, bias, gamma, beta, mean_weight, var_weight, p, k, ksize, c_out, relu):
+        require_gpu(z, "ConvSnRelu")
+        N, CZ, h, w = z.shape
+        zs, ldz = as_nhwc(z)
+        conv_out = new_nhwc(N, c_out, h * k, w * k, z.dtype, z.device)
+        b32 = None if bias is None else _f32c(bias)
+        work = float(z.element_size()) * N * c_out * (h * w * ksize * ksize + h * k * w * k)
+        _launch("upconv_fwd", work, "snws_upconv_fwd", _ptr(zs), ldz, _ptr(conv_out), c_out, _ptr(b32), dtype_code(z), N,
+                h, w, c_out, k, ksize, _stream())
+        y, sn_saved = sn_forward(conv_out, p, relu)
+        ctx.sn, ctx.meta, ctx.has_bias = sn_saved, (N, h, w, k, ksize, c_out, CZ), bias is not None
+        ctx.shapes = (gamma.shape, beta.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, h, w, k, ksize, c_out, CZ = ctx.meta
+        dconv, dg, dbeta, dmw, dvw, dxsum = sn_backward(dy, ctx.sn, want_dx_sum=True)
+        ctx.sn = None
+        dz = new_nhwc(N, CZ, h, w, dconv.dtype, dconv.device)
+        work = float(dconv.element_size()) * N * c_out * (h * w * ksize * ksize + h * k * w * k)
+        _launch("upconv_bwd", work, "snws_upconv_bwd", _ptr(dconv), c_out, _ptr(dz), CZ, dtype_code(dconv), N, h, w,
+                c_out, k, ksize, _stream())
+        db = dxsum if ctx.has_bias else None
+        return dz, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ resampling

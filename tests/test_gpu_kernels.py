@@ -371,6 +371,50 @@ def test_fused_conv_sn_relu_block_bf16_vs_oracle(shape):
     assert relerr(blk[1].running_var.view(-1), st.running_var) < 2e-3
 
 
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, h, w, k (up-sampling factor), ksize, dtype, tol
+    (2, 6, 4, 5, 7, 2, 3, torch.float32, 1e-4), (1, 5, 3, 3, 2, 8, 3, torch.float32, 1e-4),
+    (2, 8, 8, 4, 4, 16, 3, torch.float32, 1e-4), (2, 16, 8, 6, 5, 2, 1, torch.float32, 1e-4),
+    (2, 64, 64, 8, 8, 4, 3, torch.bfloat16, 2e-2), (1, 320, 64, 8, 16, 2, 3, torch.bfloat16, 2e-2),
+    (1, 128, 64, 2, 2, 16, 3, torch.bfloat16, 2e-2), (2, 64, 32, 8, 8, 2, 1, torch.bfloat16, 2e-2)])
+def test_conv_of_upsampled_map_vs_oracle(case):
+    """ConvSnRelu.on_upsampled(x, k) - the 1x1 'tap' conv at low resolution followed by the gather kernel - equals
+    ConvSnRelu(nn.Upsample(k, bilinear)(x)) of the oracle, forward and every gradient."""
+    from modeling.blocks import ConvSnRelu
+    N, Cin, Cout, h, w, k, ks, dtype, tol = case
+    torch.manual_seed(13)
+    blk = ConvSnRelu(Cin, Cout, kernel_size=ks, padding=(ks - 1) // 2).to(DEV).train()
+    with torch.no_grad():
+        blk[1].weight.copy_(torch.rand(1, Cout, 1, 1) + 0.5)
+        blk[1].bias.copy_(torch.randn(1, Cout, 1, 1) * 0.3)
+        blk[1].mean_weight.copy_(torch.randn(3))
+        blk[1].var_weight.copy_(torch.randn(3))
+    x = (torch.randn(N, Cin, h, w) * 1.5 + 0.3).to(dtype)
+    dy = torch.randn(N, Cout, h * k, w * k).to(dtype)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = blk.on_upsampled(xg, k)
+    y.backward(dy.to(DEV))
+    wr = blk[0].weight.detach().cpu().double().requires_grad_(True)
+    br = blk[0].bias.detach().cpu().double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    st = O.SNState(Cout, dtype=torch.float64)
+    st.gamma = blk[1].weight.detach().cpu().double().view(-1).requires_grad_(True)
+    st.beta = blk[1].bias.detach().cpu().double().view(-1).requires_grad_(True)
+    st.mean_weight = blk[1].mean_weight.detach().cpu().double().requires_grad_(True)
+    st.var_weight = blk[1].var_weight.detach().cpu().double().requires_grad_(True)
+    conv = O.conv2dws_fwd(O.upsample_bilinear(xr, k), wr, br, 1, (ks - 1) // 2)
+    yr, _ = O.switchnorm_fwd(conv, st, True, relu=True)
+    yr.backward(dy.double())
+    assert tuple(y.shape) == tuple(yr.shape) and y.dtype == dtype
+    assert relerr(y.float(), yr) < tol
+    assert relerr(xg.grad.float(), xr.grad) < tol
+    assert relerr(blk[0].weight.grad, wr.grad) < tol * 2 and relerr(blk[0].bias.grad, br.grad) < tol * 2
+    assert relerr(blk[1].weight.grad.view(-1), st.gamma.grad) < tol
+    assert relerr(blk[1].bias.grad.view(-1), st.beta.grad) < tol
+    assert relerr(blk[1].mean_weight.grad, st.mean_weight.grad) < 4 * tol + 1e-3
+    assert relerr(blk[1].var_weight.grad, st.var_weight.grad) < 4 * tol + 1e-3
+
+
 # ================================================================== resampling
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode,k,shape", [("maxpool", 2, (2, 16, 8, 12)), ("maxpool", 4, (1, 8, 9, 13)), ("maxpool", 8, (1, 64, 16, 16)),
