@@ -260,6 +260,27 @@ def upsample_bilinear(x, s):
     return left * (1 - lx)[None, None, None, :] + right * lx[None, None, None, :]
 
 
+def conv_of_upsampled_commuted(x, what, b, k, rnd=None):
+    """conv2d(upsample_bilinear(x, k), what, b, padding=same) evaluated in the commuted order the GPU path uses:
+    Z_t = W_t x at the source resolution, then y(p) = b + sum_t [p+t inside] up_k(Z_t)(p+t).  Equal to the direct
+    order in exact arithmetic (tests/test_oracle_golden.py checks it); rnd optionally rounds Z and y where the GPU
+    path stores them."""
+    O_, I, kh, kw = what.shape
+    pad = (kh - 1) // 2
+    rnd = rnd or (lambda t: t)
+    wre = what.permute(2, 3, 0, 1).reshape(kh * kw * O_, I, 1, 1)
+    z = rnd(F.conv2d(x, wre))
+    H, W = x.shape[2] * k, x.shape[3] * k
+    acc = 0
+    for t in range(kh * kw):
+        u = F.pad(upsample_bilinear(z[:, t * O_:(t + 1) * O_], k), (pad, pad, pad, pad))
+        dy, dx = t // kw, t % kw
+        acc = acc + u[:, :, dy:dy + H, dx:dx + W]
+    if b is not None:
+        acc = acc + b.view(1, -1, 1, 1)
+    return rnd(acc)
+
+
 def crop_concat(a, b):
     """UNet_SNws.py:35-39: centre-crop a to b's H,W (diff//2 from top/left), cat((a,b),1)."""
     dY = a.shape[2] - b.shape[2]

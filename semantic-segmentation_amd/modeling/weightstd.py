@@ -22,12 +22,12 @@ class Conv2dws(nn.Conv2d):
         self.force_direct = False   # True pins the exact direct kernels (float32 tier / debugging)
 
     def prepared(self, want_mfma):
-        """Standardized filter images, rebuilt only when the master weight changed (optimizer steps and
-        load_state_dict bump the tensor's version counter), so a module shared by several call sites in one
-        forward standardizes once."""
+        """Standardized filter images.  Rebuilt on every call, like the reference, unless a training driver has
+        switched on snws.ops.CACHE_FILTERS and announces weight updates with snws.ops.weights_changed(); then a
+        module shared by several call sites in one forward standardizes once per step."""
         w = self.weight
-        key = (w._version, w.data_ptr(), w.device, bool(want_mfma))
-        if self._prep is None or self._prep_key != key:
+        key = ops.filter_cache_key(w, want_mfma)
+        if self._prep is None or key is None or self._prep_key != key:
             cfg = ops.ConvCfg(w.shape, self.stride, self.padding, self.dilation, self.groups)
             self._prep = ops.PreparedWeight(w, cfg, want_mfma)
             self._prep_key = key
@@ -37,8 +37,8 @@ class Conv2dws(nn.Conv2d):
         """The standardized filter re-laid as a (kh*kw*O, I, 1, 1) filter for conv-of-an-up-sampled-map
         (snws.ops.TapConvFn); cached per weight version like prepared()."""
         w = self.weight
-        key = (w._version, w.data_ptr(), w.device, bool(want_mfma))
-        if self._taps is None or self._taps_key != key:
+        key = ops.filter_cache_key(w, want_mfma)
+        if self._taps is None or key is None or self._taps_key != key:
             cfg = ops.ConvCfg(w.shape, self.stride, self.padding, self.dilation, self.groups)
             if cfg.stride != 1 or cfg.dil != 1 or cfg.groups != 1 or cfg.kh != cfg.kw or cfg.kh not in (1, 3) or \
                     cfg.pad != (cfg.kh - 1) // 2:

@@ -56,7 +56,12 @@ def global_ce_loss(logits, target, ignore_index=255, group=None):
     cnt = torch.stack([(t != ignore_index).sum().to(torch.float32),
                        torch.tensor(float(n), device=logits.device)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(cnt, group=group)
+        if cnt.is_cuda and dist.get_backend(group) == "gloo":
+            h = cnt.cpu()
+            dist.all_reduce(h, group=group)
+            cnt = h.to(cnt.device)
+        else:
+            dist.all_reduce(cnt, group=group)
     return ce_sum / cnt[0] / cnt[1]
 
 
@@ -103,6 +108,14 @@ class GradBuckets:
         if not ps:
             return
         flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
+        from . import ops
+        ops.trace_collective("bucket%d" % bi, flat.numel())
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":   # test vehicle: reduce on the host, synchronously
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            flat.copy_(host)
+            self.work.append((None, flat, ps))
+            return
         h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.work.append((h, flat, ps))
 
@@ -119,7 +132,8 @@ class GradBuckets:
             if left > 0:
                 self._launch(bi)
         for h, flat, ps in self.work:
-            h.wait()
+            if h is not None:
+                h.wait()
             off = 0
             for p in ps:
                 n = p.numel()
@@ -141,6 +155,9 @@ class Trainer:
             self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb, group)
         self.it = 0
+        from . import ops
+        ops.CACHE_FILTERS = True        # this driver owns the weights: it announces every update below
+        ops.weights_changed()
 
     def step(self, image, target):
         """train.py:246-255.  Returns this rank's share of the global loss (a 0-d tensor; no host sync)."""
@@ -154,6 +171,8 @@ class Trainer:
         loss.backward()
         self.buckets.finish()
         self.opt.step()
+        from . import ops
+        ops.weights_changed()
         self.it += 1
         return loss.detach()
 

@@ -18,6 +18,24 @@ _DT = {torch.float32: L.SNWS_F32, torch.bfloat16: L.SNWS_BF16}
 PROFILE = None
 
 
+# Standardized-filter cache control.  By default a Conv2dws standardizes its filter on every call, exactly like the
+# reference.  A training driver that knows when weights change (snws.harness.Trainer) sets CACHE_FILTERS = True and
+# calls weights_changed() after every optimizer step / state_dict load; then a module shared by several call sites
+# standardizes once per step.  (Tensor version counters are not a safe key: fused optimizers update in place
+# without bumping them.)
+CACHE_FILTERS = False
+WEIGHT_EPOCH = 0
+
+
+def weights_changed():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def filter_cache_key(w, want_mfma):
+    return (WEIGHT_EPOCH, w._version, w.data_ptr(), str(w.device), bool(want_mfma)) if CACHE_FILTERS else None
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -231,7 +249,25 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db):
 # ------------------------------------------------------------------------------------------------ SwitchNorm
 def _allreduce_sum(t, group):
     import torch.distributed as dist
+    trace_collective("sn", t.numel())
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo is only the single-GPU / CPU test vehicle: stage the few hundred bytes through the host explicitly
+        # (its own device-tensor path stalls when ranks share one GPU); RCCL takes the device tensor directly
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def trace_collective(kind, numel):
+    """SNWS_TRACE_COLLECTIVES=<dir>: append every collective this rank issues to <dir>/coll_rank<r>.log (debug aid
+    for order mismatches between ranks)."""
+    import os
+    d = os.environ.get("SNWS_TRACE_COLLECTIVES")
+    if d:
+        with open(os.path.join(d, "coll_rank%s.log" % os.environ.get("RANK", "0")), "a") as f:
+            f.write("%s %d\n" % (kind, numel))
 
 
 def sync_world(group=None):

@@ -85,6 +85,8 @@ class Evaluator(object):
         if all_reduce:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                if dist.get_backend(group) == "gloo":
+                    c = c.cpu()
                 dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
         host = c.cpu().numpy()
         self._counts = None

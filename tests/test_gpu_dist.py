@@ -31,6 +31,8 @@ def _worker(rank, world, port, q):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import faulthandler
+    faulthandler.dump_traceback_later(80, exit=True)     # a stuck collective shows where, instead of hanging the run
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import patterns
     from modeling.UNet3p_SNws import UNet3p_SNws
@@ -47,7 +49,7 @@ def _worker(rank, world, port, q):
     loss = harness.global_ce_loss(logits, lab[rank:rank + 1].to(dev))
     loss.backward()
     buckets.finish()
-    tot = loss.detach().clone()
+    tot = loss.detach().cpu()
     dist.all_reduce(tot)
     errs = {"logits": float(np.abs(logits.detach().cpu().numpy() - g["logits"][rank:rank + 1]).max() /
                             np.abs(g["logits"]).max()),
@@ -81,7 +83,7 @@ def test_two_rank_step_equals_reference_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=100) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

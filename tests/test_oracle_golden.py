@@ -176,6 +176,18 @@ def test_upsample_bilinear(s):
     close(O.upsample_bilinear(x, s), ref, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("k,ks", [(2, 3), (4, 3), (16, 3), (8, 1)])
+def test_conv_of_upsampled_commutes(k, ks):
+    """The identity behind the GPU path's conv-of-upsample: contracting channels at the source resolution and
+    interpolating afterwards equals convolving the up-sampled map (borders included)."""
+    x = torch.from_numpy(patterns.fill((2, 5, 3, 4), k, 1.0)).double()
+    w = torch.from_numpy(patterns.fill((6, 5, ks, ks), k + 1, 0.8)).double()
+    b = torch.from_numpy(patterns.fill((6,), k + 2, 0.3)).double()
+    what = O.ws_standardize(w)
+    direct = torch.nn.functional.conv2d(O.upsample_bilinear(x, k), what, b, 1, (ks - 1) // 2)
+    close(O.conv_of_upsampled_commuted(x, what, b, k), direct, rtol=1e-12, atol=1e-12)
+
+
 # ---------------------------------------------------------------- whole models
 def _state_from_pattern(arch, nf=4):
     st = O.make_state(arch, 14, nf, 10)
