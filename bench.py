@@ -59,6 +59,30 @@ def cpu_baseline(n_filters, size, seconds_budget=30.0):
                       "(=%.4g of a %dx%d image), %.1f s" % (n_filters, side, side, frac, size, size, dt)}
 
 
+def evaluator_throughput(device, reps=20):
+    """Evaluator.add_batch on one full FY-4A disk (1 x 2748 x 2748, f32 labels + i64 predictions, 10 classes,
+    both resident in HBM): 12 algorithmic bytes per pixel."""
+    from utils.metrics import Evaluator
+    g = torch.Generator(device="cpu").manual_seed(0)
+    gt = torch.randint(0, 10, (1, 2748, 2748), generator=g).float().to(device)
+    pr = torch.randint(0, 10, (1, 2748, 2748), generator=g).to(device)
+    ev = Evaluator(10)
+    ev.add_batch(gt, pr)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ev.add_batch(gt, pr)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    npix = gt.numel()
+    ev.sync()
+    return {"workload": "Evaluator.add_batch, 1x2748x2748 f32 gt + i64 pred, 10 classes", "us_per_disk": sec * 1e6,
+            "Mpix/s": npix / sec / 1e6, "GB/s": 12.0 * npix / sec / 1e9,
+            "frac_of_hbm_peak": 12.0 * npix / sec / 1e9 / HBM_PEAK_GBS, "mIoU": float(ev.Mean_Intersection_over_Union())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +174,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "loss": loss_val, "roofline": roofline, "kernels": summary,
         }
+        out["evaluator"] = evaluator_throughput(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.filters, args.size)
         print(json.dumps(out), flush=True)

@@ -1,15 +1,21 @@
 // Confusion-matrix histogram for the Evaluator (replaces utils/metrics.py:40-45 of the reference).
 //
-// HBM-bound integer work: every pixel is read once (label + prediction, 12 B/pixel for f32 + i64) and costs
-// one LDS integer atomic into a per-wave private histogram; a block flushes its non-zero bins with 64-bit
-// global atomics at the end, so the result is exact and independent of scheduling.
+// HBM-bound integer work: every pixel is read once (label + prediction, 12 B/pixel for f32 + i64; 16/32-byte
+// loads, 4 pixels per lane) and costs one LDS integer atomic into a per-wave private histogram; one 1024-thread
+// workgroup per CU flushes its non-zero bins with 64-bit global atomics at the end, so the result is exact and
+// independent of scheduling.
 #include "common.h"
 
 namespace {
 
-constexpr int HIST_THREADS = 256;
+constexpr int HIST_THREADS = 1024;              // 16 waves per workgroup, one workgroup per CU
 constexpr int HIST_WAVES = HIST_THREADS / 64;
-constexpr int HIST_MAX_BLOCKS = 1024;
+constexpr int HIST_MAX_BLOCKS = 256;            // few blocks: the final same-address 64-bit atomics serialise per bin
+
+template <typename T>
+struct alignas(sizeof(T) * 4) Pack4 {
+  T v[4];
+};
 
 template <typename G>
 __device__ __forceinline__ bool label_ok(G g, int C, int& gi) {
@@ -26,28 +32,52 @@ __device__ __forceinline__ void count(unsigned* h, int C2, bool ok, int gi, int6
   atomicAdd(&h[bin], 1u);
 }
 
-template <typename G, typename P>
+template <typename G, typename P, bool VEC>
 __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const G* __restrict__ gt, const P* __restrict__ pred,
-                                                            int64_t n, int C, unsigned long long* counts) {
+                                                            int64_t n, int C, int copies, unsigned long long* counts) {
   extern __shared__ __attribute__((aligned(16))) unsigned hist_lds[];
   const int C2 = C * C, bins = C2 + 2;
-  for (int i = threadIdx.x; i < bins * HIST_WAVES; i += HIST_THREADS) hist_lds[i] = 0;
+  for (int i = threadIdx.x; i < bins * copies; i += HIST_THREADS) hist_lds[i] = 0;
   __syncthreads();
-  unsigned* h = hist_lds + (threadIdx.x >> 6) * bins;
-  const int64_t stride = (int64_t)gridDim.x * HIST_THREADS;
-  // 4 pixels per thread per step keeps several independent loads in flight
-  int64_t i = ((int64_t)blockIdx.x * HIST_THREADS + threadIdx.x);
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    G g0 = gt[i], g1 = gt[i + stride], g2 = gt[i + 2 * stride], g3 = gt[i + 3 * stride];
-    P p0 = pred[i], p1 = pred[i + stride], p2 = pred[i + 2 * stride], p3 = pred[i + 3 * stride];
-    int a0, a1, a2, a3;
-    bool k0 = label_ok(g0, C, a0), k1 = label_ok(g1, C, a1), k2 = label_ok(g2, C, a2), k3 = label_ok(g3, C, a3);
-    count(h, C2, k0, a0, (int64_t)p0, C);
-    count(h, C2, k1, a1, (int64_t)p1, C);
-    count(h, C2, k2, a2, (int64_t)p2, C);
-    count(h, C2, k3, a3, (int64_t)p3, C);
+  unsigned* h = hist_lds + ((threadIdx.x >> 6) % copies) * bins;
+  const int64_t nthreads = (int64_t)gridDim.x * HIST_THREADS;
+  const int64_t tid = (int64_t)blockIdx.x * HIST_THREADS + threadIdx.x;
+  int64_t done = 0;
+  if (VEC) {
+    // 4 consecutive pixels per lane per load (16 B of f32 labels, 32 B of i64 predictions), two loads in flight
+    const int64_t n4 = n >> 2;
+    const Pack4<G>* g4 = reinterpret_cast<const Pack4<G>*>(gt);
+    const Pack4<P>* p4 = reinterpret_cast<const Pack4<P>*>(pred);
+    int64_t i = tid;
+    for (; i + nthreads < n4; i += 2 * nthreads) {
+      const Pack4<G> ga = g4[i], gb = g4[i + nthreads];
+      const Pack4<P> pa = p4[i], pb = p4[i + nthreads];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int a;
+        bool k = label_ok(ga.v[e], C, a);
+        count(h, C2, k, a, (int64_t)pa.v[e], C);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int a;
+        bool k = label_ok(gb.v[e], C, a);
+        count(h, C2, k, a, (int64_t)pb.v[e], C);
+      }
+    }
+    for (; i < n4; i += nthreads) {
+      const Pack4<G> ga = g4[i];
+      const Pack4<P> pa = p4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int a;
+        bool k = label_ok(ga.v[e], C, a);
+        count(h, C2, k, a, (int64_t)pa.v[e], C);
+      }
+    }
+    done = n4 << 2;
   }
-  for (; i < n; i += stride) {
+  for (int64_t i = done + tid; i < n; i += nthreads) {
     int a;
     bool k = label_ok(gt[i], C, a);
     count(h, C2, k, a, (int64_t)pred[i], C);
@@ -55,7 +85,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const G* __restrict_
   __syncthreads();
   for (int b = threadIdx.x; b < bins; b += HIST_THREADS) {
     unsigned long long s = 0;
-    for (int w = 0; w < HIST_WAVES; ++w) s += hist_lds[w * bins + b];
+    for (int w = 0; w < copies; ++w) s += hist_lds[w * bins + b];
     if (s) atomicAdd(&counts[b], s);
   }
 }
@@ -63,12 +93,12 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const G* __restrict_
 template <typename G, typename L>
 __global__ __launch_bounds__(HIST_THREADS) void hist_argmax_kernel(const G* __restrict__ gt,
                                                                    const L* __restrict__ logits, int64_t ld,
-                                                                   int64_t n, int C, unsigned long long* counts) {
+                                                                   int64_t n, int C, int copies, unsigned long long* counts) {
   extern __shared__ __attribute__((aligned(16))) unsigned hist_lds[];
   const int C2 = C * C, bins = C2 + 2;
-  for (int i = threadIdx.x; i < bins * HIST_WAVES; i += HIST_THREADS) hist_lds[i] = 0;
+  for (int i = threadIdx.x; i < bins * copies; i += HIST_THREADS) hist_lds[i] = 0;
   __syncthreads();
-  unsigned* h = hist_lds + (threadIdx.x >> 6) * bins;
+  unsigned* h = hist_lds + ((threadIdx.x >> 6) % copies) * bins;
   const int64_t stride = (int64_t)gridDim.x * HIST_THREADS;
   for (int64_t i = (int64_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < n; i += stride) {
     int gi;
@@ -86,13 +116,19 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_argmax_kernel(const G* __re
   __syncthreads();
   for (int b = threadIdx.x; b < bins; b += HIST_THREADS) {
     unsigned long long s = 0;
-    for (int w = 0; w < HIST_WAVES; ++w) s += hist_lds[w * bins + b];
+    for (int w = 0; w < copies; ++w) s += hist_lds[w * bins + b];
     if (s) atomicAdd(&counts[b], s);
   }
 }
 
+// private histogram copies per workgroup: one per wave while they fit in 48 KB of LDS
+int hist_copies(int C) {
+  int c = (48 * 1024) / ((C * C + 2) * 4);
+  return c < 1 ? 1 : (c > HIST_WAVES ? HIST_WAVES : c);
+}
+
 int hist_grid(int64_t n) {
-  int64_t b = cdiv64(n, (int64_t)HIST_THREADS * 16);
+  int64_t b = cdiv64(n, (int64_t)HIST_THREADS * 8);
   if (b < 1) b = 1;
   if (b > HIST_MAX_BLOCKS) b = HIST_MAX_BLOCKS;
   return (int)b;
@@ -101,15 +137,23 @@ int hist_grid(int64_t n) {
 template <typename G>
 int launch_hist_p(const void* gt, const void* pred, int pred_dtype, int64_t n, int C, int64_t* counts,
                   hipStream_t st) {
-  const size_t lds = (size_t)(C * C + 2) * HIST_WAVES * sizeof(unsigned);
+  const int copies = hist_copies(C);
+  const size_t lds = (size_t)(C * C + 2) * copies * sizeof(unsigned);
   auto* out = reinterpret_cast<unsigned long long*>(counts);
   dim3 grid(hist_grid(n)), block(HIST_THREADS);
+  auto aligned = [](const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; };
+#define HK(PT)                                                                                             \
+  if (aligned(gt, sizeof(G) * 4) && aligned(pred, sizeof(PT) * 4))                                         \
+    hist_kernel<G, PT, true><<<grid, block, lds, st>>>((const G*)gt, (const PT*)pred, n, C, copies, out);          \
+  else                                                                                                     \
+    hist_kernel<G, PT, false><<<grid, block, lds, st>>>((const G*)gt, (const PT*)pred, n, C, copies, out);
   switch (pred_dtype) {
-    case SNWS_I64: hist_kernel<G, int64_t><<<grid, block, lds, st>>>((const G*)gt, (const int64_t*)pred, n, C, out); break;
-    case SNWS_I32: hist_kernel<G, int32_t><<<grid, block, lds, st>>>((const G*)gt, (const int32_t*)pred, n, C, out); break;
-    case SNWS_U8: hist_kernel<G, uint8_t><<<grid, block, lds, st>>>((const G*)gt, (const uint8_t*)pred, n, C, out); break;
+    case SNWS_I64: HK(int64_t) break;
+    case SNWS_I32: HK(int32_t) break;
+    case SNWS_U8: HK(uint8_t) break;
     default: snws_set_error("snws_confusion_hist: pred_dtype %d not one of I64/I32/U8", pred_dtype); return SNWS_ERR_INVALID;
   }
+#undef HK
   SNWS_LAUNCH_CHECK("snws_confusion_hist");
   return SNWS_OK;
 }
@@ -117,13 +161,14 @@ int launch_hist_p(const void* gt, const void* pred, int pred_dtype, int64_t n, i
 template <typename G>
 int launch_hist_argmax_l(const void* gt, const void* logits, int logit_dtype, int64_t ld, int64_t n, int C,
                          int64_t* counts, hipStream_t st) {
-  const size_t lds = (size_t)(C * C + 2) * HIST_WAVES * sizeof(unsigned);
+  const int copies = hist_copies(C);
+  const size_t lds = (size_t)(C * C + 2) * copies * sizeof(unsigned);
   auto* out = reinterpret_cast<unsigned long long*>(counts);
   int64_t b = cdiv64(n, HIST_THREADS * 4);
   dim3 grid((unsigned)(b < 1 ? 1 : (b > HIST_MAX_BLOCKS ? HIST_MAX_BLOCKS : b))), block(HIST_THREADS);
   switch (logit_dtype) {
-    case SNWS_F32: hist_argmax_kernel<G, float><<<grid, block, lds, st>>>((const G*)gt, (const float*)logits, ld, n, C, out); break;
-    case SNWS_BF16: hist_argmax_kernel<G, bf16_t><<<grid, block, lds, st>>>((const G*)gt, (const bf16_t*)logits, ld, n, C, out); break;
+    case SNWS_F32: hist_argmax_kernel<G, float><<<grid, block, lds, st>>>((const G*)gt, (const float*)logits, ld, n, C, copies, out); break;
+    case SNWS_BF16: hist_argmax_kernel<G, bf16_t><<<grid, block, lds, st>>>((const G*)gt, (const bf16_t*)logits, ld, n, C, copies, out); break;
     default: snws_set_error("snws_confusion_hist_argmax: logit_dtype %d not F32/BF16", logit_dtype); return SNWS_ERR_INVALID;
   }
   SNWS_LAUNCH_CHECK("snws_confusion_hist_argmax");

@@ -76,6 +76,22 @@ def test_evaluator_full_disk_bit_exact():
     assert np.array_equal(ev2._matrix(), 2 * g["d_cm"])
 
 
+def test_evaluator_many_classes_and_unaligned():
+    """64 classes (LDS histogram copies are limited) and inputs whose base address is not 16-byte aligned."""
+    from utils.metrics import Evaluator
+    rng = np.random.default_rng(5)
+    gt = rng.integers(0, 70, size=(3, 33, 47)).astype(np.float32)
+    pr = rng.integers(0, 64, size=(3, 33, 47)).astype(np.int64)
+    ev = Evaluator(64)
+    ev.add_batch(gt, pr)
+    assert np.array_equal(ev.confusion_matrix, O.confusion_matrix(gt, pr, 64).astype(np.float64))
+    g1 = torch.from_numpy(gt.reshape(-1)).to(DEV)[1:]
+    p1 = torch.from_numpy(pr.reshape(-1)).to(DEV)[1:]
+    ev = Evaluator(64)
+    ev.add_batch(g1, p1)
+    assert np.array_equal(ev._matrix(), O.confusion_matrix(gt.reshape(-1)[1:], pr.reshape(-1)[1:], 64).astype(np.float64))
+
+
 def test_evaluator_out_of_range_prediction_raises():
     from utils.metrics import Evaluator
     ev = Evaluator(10)
