@@ -47,18 +47,23 @@ class UNet3p_SNws(nn.Module):
         z5 = self.conv5_cat.taps(enc[5])
         zdec = {}
         dec = {}
+        f = self.Cat_channels
         for level in (4, 3, 2, 1):
+            # the five 64-channel blocks write straight into their channel slice of the fusion input: no torch.cat
+            ref = enc[level]
+            buf = ops.new_nhwc(ref.shape[0], 5 * f, ref.shape[2], ref.shape[3], ref.dtype, ref.device)
             parts = []
             for src in (1, 2, 3, 4):
+                out = buf[:, len(parts) * f:(len(parts) + 1) * f]
                 if src < level:         # encoder map, max-pooled down to this level
-                    parts.append(enc_cat[src](ops.max_pool_ceil(enc[src], 2 ** (level - src))))
+                    parts.append(enc_cat[src](ops.max_pool_ceil(enc[src], 2 ** (level - src)), out=out))
                 elif src == level:
-                    parts.append(enc_cat[src](enc[src]))
+                    parts.append(enc_cat[src](enc[src], out=out))
                 else:                   # decoder map of a coarser level, up-sampled
                     if src not in zdec:
                         zdec[src] = self.convu_cat.taps(dec[src])
-                    parts.append(self.convu_cat.up(zdec[src], 2 ** (src - level)))
+                    parts.append(self.convu_cat.up(zdec[src], 2 ** (src - level), out=out))
             # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
-            parts.append(self.conv5_cat.up(z5, 2 ** (5 - level)))
-            dec[level] = self.conv_fusion(torch.cat(parts, 1))
+            parts.append(self.conv5_cat.up(z5, 2 ** (5 - level), out=buf[:, 4 * f:5 * f]))
+            dec[level] = self.conv_fusion(ops.AssembleFn.apply(buf, *parts))
         return head_conv(self.output_seg_map, dec[1])

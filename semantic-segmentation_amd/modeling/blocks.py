@@ -21,7 +21,8 @@ class ConvSnRelu(nn.Sequential):
             sn.SwitchNorm2d(out_channels, using_movavg=using_movavg, using_bn=using_bn, last_gamma=last_gamma),
             nn.ReLU())
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: optional channels-last destination (e.g. a channel slice of a concat buffer) for the block output."""
         conv, norm = self[0], self[1]
         if x.dim() != 4:
             raise ValueError('expected 4D input (got {}D input)'.format(x.dim()))
@@ -29,10 +30,13 @@ class ConvSnRelu(nn.Sequential):
         prep = conv.prepared(x.dtype == torch.bfloat16 and not conv.force_direct)
         if conv.force_direct:
             y = ops.Conv2dwsFn.apply(x, conv.weight, conv.bias, prep, True)
-            return ops.SwitchNormFn.apply(y, norm.weight, norm.bias, norm.mean_weight, norm.var_weight,
-                                          ops.SNParams(norm), True)
+            y = ops.SwitchNormFn.apply(y, norm.weight, norm.bias, norm.mean_weight, norm.var_weight,
+                                       ops.SNParams(norm), True)
+            if out is not None:
+                raise NotImplementedError("out= is not available with force_direct")
+            return y
         return ops.ConvSnReluFn.apply(x, conv.weight, conv.bias, norm.weight, norm.bias, norm.mean_weight,
-                                      norm.var_weight, prep, ops.SNParams(norm), True)
+                                      norm.var_weight, prep, ops.SNParams(norm), True, out)
 
 
     # ---- the block applied to nn.Upsample(scale_factor=k, mode='bilinear')(x), without building the up-sampled map
@@ -43,10 +47,10 @@ class ConvSnRelu(nn.Sequential):
         tp = conv.prepared_taps(x.dtype == torch.bfloat16 and not conv.force_direct)
         return ops.TapConvFn.apply(x, conv.weight, tp)
 
-    def up(self, z, k):
+    def up(self, z, k, out=None):
         conv, norm = self[0], self[1]
         return ops.UpTapSnReluFn.apply(z, conv.bias, norm.weight, norm.bias, norm.mean_weight, norm.var_weight,
-                                       ops.SNParams(norm), int(k), conv.kernel_size[0], conv.out_channels, True)
+                                       ops.SNParams(norm), int(k), conv.kernel_size[0], conv.out_channels, True, out)
 
     def on_upsampled(self, x, k):
         """== self(nn.Upsample(scale_factor=k, mode='bilinear', align_corners=False)(x))."""

@@ -297,7 +297,7 @@ def _f32c(t):
     return (t if t.dtype == torch.float32 else t.float()).contiguous()
 
 
-def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None):
+def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=None):
     """SwitchNorm (+ReLU) of the logical (N,C,H,W) tensor x.  stat_part/stat_shift: partial moments from the
     conv epilogue (then x is not re-read for statistics).  Returns (y, saved)."""
     require_gpu(x, "SwitchNorm2d")
@@ -333,11 +333,19 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None):
         raise TypeError("SwitchNorm2d running buffers must be contiguous float32")
     L.call("snws_sn_mix_b", _ptr(ctx), _ptr(pack), _ptr(gamma), _ptr(mw), _ptr(vw), _ptr(rm), _ptr(rv), N, C,
            p.eps, p.momentum, int(p.training), int(p.using_movavg), int(p.using_bn), st)
-    y = new_nhwc(N, C, H, W, x.dtype, dev)
+    if out is None:
+        y, ldy = new_nhwc(N, C, H, W, x.dtype, dev), C
+    else:       # caller-provided destination, e.g. a channel slice of a concat buffer
+        if tuple(out.shape) != (N, C, H, W) or out.dtype != x.dtype:
+            raise ValueError("SwitchNorm2d: out has shape %s / dtype %s, expected %s / %s"
+                             % (tuple(out.shape), out.dtype, (N, C, H, W), x.dtype))
+        y, ldy = as_nhwc(out)
+        if y.data_ptr() != out.data_ptr():
+            raise ValueError("SwitchNorm2d: out must be channels-last (or a channel slice of a channels-last tensor)")
     rs, ldr = (None, 0)
     if residual is not None:
         rs, ldr = as_nhwc(residual.to(x.dtype))
-    _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), C, _ptr(rs), ldr,
+    _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), ldy, _ptr(rs), ldr,
             dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
     n_global = float(N * world) if world > 1 else float(N)
     saved = dict(xs=xs, ldx=ldx, ctx=ctx, gamma=gamma, beta=beta, mw=mw, vw=vw, relu=bool(relu), shape=(N, C, H, W),
@@ -452,13 +460,13 @@ class ConvSnReluFn(torch.autograd.Function):
     partial moments, SwitchNorm applies the ReLU, and only the conv output is kept for backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, mean_weight, var_weight, prep, p, relu):
+    def forward(ctx, x, weight, bias, gamma, beta, mean_weight, var_weight, prep, p, relu, out=None):
         conv_out, stat, saved = conv_forward(x, prep, bias, want_stats=True)
         shift = None
         if stat is not None:
             shift = _f32c(bias) if bias is not None else torch.zeros(weight.shape[0], dtype=torch.float32,
                                                                        device=x.device)
-        y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift)
+        y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift, out=out)
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.save_for_backward(weight)
@@ -474,7 +482,7 @@ class ConvSnReluFn(torch.autograd.Function):
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
-        return dx, dw, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None
+        return dx, dw, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ conv of an up-sampled map
@@ -527,7 +535,7 @@ class UpTapSnReluFn(torch.autograd.Function):
     ConvSnRelu(nn.Upsample(k)(x)), modeling/UNet3p_SNws.py:131-155, with the block's SwitchNorm + ReLU."""
 
     @staticmethod
-    def forward(ctx, z, bias, gamma, beta, mean_weight, var_weight, p, k, ksize, c_out, relu):
+    def forward(ctx, z, bias, gamma, beta, mean_weight, var_weight, p, k, ksize, c_out, relu, out=None):
         require_gpu(z, "ConvSnRelu")
         N, CZ, h, w = z.shape
         zs, ldz = as_nhwc(z)
@@ -536,7 +544,7 @@ class UpTapSnReluFn(torch.autograd.Function):
         work = float(z.element_size()) * N * c_out * (h * w * ksize * ksize + h * k * w * k)
         _launch("upconv_fwd", work, "snws_upconv_fwd", _ptr(zs), ldz, _ptr(conv_out), c_out, _ptr(b32), dtype_code(z), N,
                 h, w, c_out, k, ksize, _stream())
-        y, sn_saved = sn_forward(conv_out, p, relu)
+        y, sn_saved = sn_forward(conv_out, p, relu, out=out)
         ctx.sn, ctx.meta, ctx.has_bias = sn_saved, (N, h, w, k, ksize, c_out, CZ), bias is not None
         ctx.shapes = (gamma.shape, beta.shape)
         return y
@@ -551,7 +559,34 @@ class UpTapSnReluFn(torch.autograd.Function):
         _launch("upconv_bwd", work, "snws_upconv_bwd", _ptr(dconv), c_out, _ptr(dz), CZ, dtype_code(dconv), N, h, w,
                 c_out, k, ksize, _stream())
         db = dxsum if ctx.has_bias else None
-        return dz, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None, None, None
+        return dz, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None, None, None, None
+
+
+class AssembleFn(torch.autograd.Function):
+    """torch.cat((parts...), 1) without the copy: the parts were written by their producers straight into channel
+    slices of `buf` (the `out=` argument of the fused blocks); forward hands out `buf`, backward hands every
+    producer its channel slice of the gradient as a strided view (the kernels take a pixel stride)."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        off = 0
+        for t in parts:
+            c = t.shape[1]
+            if t.data_ptr() != buf[:, off:off + c].data_ptr() or t.shape[2:] != buf.shape[2:]:
+                raise ValueError("AssembleFn: part is not the matching channel slice of the buffer")
+            off += c
+        if off != buf.shape[1]:
+            raise ValueError("AssembleFn: parts cover %d of %d channels" % (off, buf.shape[1]))
+        ctx.widths = [t.shape[1] for t in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [None], 0
+        for c in ctx.widths:
+            outs.append(g[:, off:off + c])
+            off += c
+        return tuple(outs)
 
 
 # ------------------------------------------------------------------------------------------------ resampling
