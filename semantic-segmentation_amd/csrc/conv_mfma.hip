@@ -21,11 +21,13 @@
 //   its result to the f32 gradient with float atomics (128-byte segments per wave-instruction).
 #include "common.h"
 #include "pack.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(8))) short short8v;
 
@@ -70,21 +72,35 @@ struct FwdGeom {
   static constexpr int JIN = (NI + 3) / 4, JW = (NIW + 3) / 4;
   static constexpr int MAIN_BYTES = IN_BYTES + W_BYTES;
   static constexpr int LDS_BYTES = (MAIN_BYTES > OUT_BYTES + STAT_BYTES) ? MAIN_BYTES : OUT_BYTES + STAT_BYTES;
+  // double-buffered variant: every wave issues the same number of LDS-DMA loads per chunk (so one counted
+  // s_waitcnt retires exactly the previous chunk), hence the input region is rounded up to 4*JIN pieces
+  // (filter pieces that do not divide by 4 are topped up with repeats of a wave's own previous piece)
+  static constexpr int IN_BYTES_DB = JIN * 4 * 1024, STAGE_DB = IN_BYTES_DB + W_BYTES, NLOAD_DB = JIN + JW;
+  static constexpr int LDS_BYTES_DB = (2 * STAGE_DB > OUT_BYTES + STAT_BYTES) ? 2 * STAGE_DB : OUT_BYTES + STAT_BYTES;
 };
 
 // 16-byte-chunk XOR swizzle of a halo pixel, a function of its COLUMN only: a ds_read_b128 lane group reads 16
 // consecutive columns of one row, and the row then enters the address as a compile-time immediate.
-template <int VPP>
+// (the 16x16x32 fragment shape puts 16 columns x one chunk in a lane group and needs a different XOR pattern)
+template <int VPP, bool M16>
 __device__ __forceinline__ int col_swz(int px) {
-  return VPP == 4 ? ((px >> 2) & 3) : ((px >> 3) & 1);
+  return M16 ? ((px >> 2) & 1) * 2 : VPP == 4 ? ((px >> 2) & 3) : ((px >> 3) & 1);
 }
 
-template <int KC, int TAPS>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(FwdArgs a) {
+// DB = false: one LDS stage, two workgroups per CU hide each other's staging.
+// DB = true : two LDS stages in one workgroup per CU; the next chunk's LDS-DMA is issued before the current chunk's
+//             MFMAs and retired by a counted s_waitcnt + raw s_barrier, so staging overlaps the matrix work.
+// M16      : v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (KC = 32 only).  Same FLOPs per cycle and the same LDS
+//             bytes per FLOP, but the chip holds a higher clock under this shape.
+template <int KC, int TAPS, bool DB, bool M16>
+__global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kernel(FwdArgs a) {
+  static_assert(!M16 || KC == 32, "the 16x16x32 shape contracts 32 channels per instruction");
   using G = FwdGeom<KC, TAPS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int IN_B = DB ? G::IN_BYTES_DB : G::IN_BYTES;
+  constexpr int STAGE = DB ? G::STAGE_DB : 0;
   unsigned char* in_lds = smem;
-  unsigned char* w_lds = smem + G::IN_BYTES;
+  unsigned char* w_lds = smem + IN_B;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,82 +122,197 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(FwdArgs a) {
     const int pix = i * G::PPI + lane / G::VPP;
     const int py = pix / G::HWd, px = pix - py * G::HWd;
     const int gy = y0 - G::PADK + py, gx = x0 - G::PADK + px;
-    const bool ok = (i < G::NI) && (pix < G::NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const int chunk = (lane % G::VPP) ^ col_swz<G::VPP>(px);
+    const bool ok = (pix < G::NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int chunk = (lane % G::VPP) ^ col_swz<G::VPP, M16>(px);
     src[j] = ok ? (unsigned)((((int64_t)gy * a.W + gx) * a.ldx + chunk * 8) * 2) : ~0u;
   }
 
-  f32x16 acc[2][4];
+  // accumulators: 32x32x16: acc[c2][p] = out channels c2*32.. x tile row p (32 pixels), 16 floats;
+  //               16x16x32: acc16[c4][2p+hf] = out channels c4*16.. x columns hf*16.. of tile row p, 4 floats
+  f32x16 acc[M16 ? 1 : 2][M16 ? 1 : 4];
+  f32x4 acc16[M16 ? 4 : 1][M16 ? 8 : 1];
+  if constexpr (M16) {
 #pragma unroll
-  for (int c2 = 0; c2 < 2; ++c2)
+    for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < 8; ++p)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c2][p][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc16[c4][p][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c2][p][r] = 0.f;
+  }
 
-  const int r = lane & 31, h = lane >> 5;
+  const int r = M16 ? (lane & 15) : (lane & 31), h = M16 ? (lane >> 4) : (lane >> 5);
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.pack) + (int64_t)ct * a.nchunks * G::W_BYTES;
-  // LDS read bases: one per (kw, k-step) for the pixel operand (tile rows and kh are immediates), one for the filter
+  // LDS read bases: one per (kw, k-step) for the pixel operand (tile rows and kh are immediates), one for the filter.
+  // 16x16x32: lane = (column r of 16, 8-channel quarter h of the 32-channel chunk); one k-step per chunk.
   constexpr int KWN = TAPS == 9 ? 3 : 1;
-  const unsigned char* bbase[KWN][G::KS];
+  constexpr int KSB = M16 ? 1 : G::KS;
+  const unsigned char* bbase[KWN][KSB];
 #pragma unroll
   for (int kw = 0; kw < KWN; ++kw)
 #pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks)
-      bbase[kw][ks] = in_lds + (wave * 4 * G::HWd + r + kw) * G::PIXB + (((ks * 2 + h) ^ col_swz<G::VPP>(r + kw)) * 16);
-  const unsigned char* abase = w_lds + h * 1024 + r * 16;
+    for (int ks = 0; ks < KSB; ++ks)
+      bbase[kw][ks] = in_lds + (wave * 4 * G::HWd + r + kw) * G::PIXB +
+                      (((M16 ? h : ks * 2 + h) ^ col_swz<G::VPP, M16>(r + kw)) * 16);
+  const unsigned char* abase = M16 ? w_lds + (h >> 1) * 2048 + (h & 1) * 1024 + r * 16 : w_lds + h * 1024 + r * 16;
 
-  for (int ch = 0; ch < a.nchunks; ++ch) {
-    // ---- stage this chunk: halo patch + filter slab
+  // ---- stage chunk ch into LDS stage `so` (byte offset): halo patch + filter slab
+  auto stage = [&](int ch, int so) {
 #pragma unroll
     for (int j = 0; j < G::JIN; ++j) {
       const int i = wave + 4 * j;
-      if (i < G::NI) {
+      if (DB || i < G::NI) {
         const unsigned char* p = src[j] == ~0u ? reinterpret_cast<const unsigned char*>(snws_zero_page)
                                                : img + src[j] + ch * (KC * 2);
-        glds16(p, in_lds + i * 1024);
+        glds16(p, in_lds + so + i * 1024);
       }
     }
     const unsigned char* wslab = wbase + (int64_t)ch * G::W_BYTES + lane * 16;
 #pragma unroll
     for (int j = 0; j < G::JW; ++j) {
-      const int i = wave + 4 * j;
-      if (i < G::NIW) glds16(wslab + i * 1024, w_lds + i * 1024);
+      int i = wave + 4 * j;
+      if (DB && i >= G::NIW) i -= 4;   // keep the per-wave load count uniform: repeat this wave's previous piece
+      if (i < G::NIW) glds16(wslab + i * 1024, w_lds + so + i * 1024);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+  // ---- MFMAs of one chunk: every tap reads its shifted fragments from the same halo patch.
+  // Work is cut into groups g = (kw, k-step, kh) of 8 MFMAs.  The 4 + (KHN-1) pixel-row fragments of a (kw, k-step)
+  // set serve all its kh groups; a software pipeline reads the next group's two filter fragments and a share of
+  // the next set's pixel fragments while the current group's MFMAs run (two register sets each).
+  auto compute32 = [&](int so) {
+    constexpr int KHN = TAPS == 9 ? 3 : 1, NB = 4 + KHN - 1, NS = KWN * G::KS, NG = NS * KHN, BPG = (NB + KHN - 1) / KHN;
+    bf16x8 A[2][2], B[2][NB];
+    auto load_a = [&](int g) {
+      const int s_ = g / KHN, kh = g % KHN, kw = s_ / G::KS, ks = s_ % G::KS;
+      const int tap = kh * 3 + kw;
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+        A[g & 1][c2] = *reinterpret_cast<const bf16x8*>(abase + so + (tap * G::KS + ks) * 2048 + c2 * 512);
+    };
+    auto load_b = [&](int s_, int part) {
+      const int kw = s_ / G::KS, ks = s_ % G::KS;
+#pragma unroll
+      for (int q = part * BPG; q < (part + 1) * BPG && q < NB; ++q)
+        B[s_ & 1][q] = *reinterpret_cast<const bf16x8*>(bbase[kw][ks] + so + q * (G::HWd * G::PIXB));
+    };
+#pragma unroll
+    for (int part = 0; part < KHN; ++part) load_b(0, part);
+    load_a(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int s_ = g / KHN, kh = g % KHN;
+      if (g + 1 < NG) load_a(g + 1);
+      if (s_ + 1 < NS) load_b(s_ + 1, kh);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          acc[c2][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[g & 1][c2], B[s_ & 1][p + kh], acc[c2][p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
-    // ---- MFMAs: every tap reads its shifted fragments from the same halo patch
+  // 16x16x32: steps (kw, input row rho of the wave's 4 + KHN - 1 halo rows).  A row's two 16-column fragments feed
+  // every (kh, tile row p) with p + kh = rho; the filter fragments of the three kh of a kw stay in registers and
+  // are replaced one kh at a time as soon as their last use is behind (single register set).
+  auto compute16 = [&](int so) {
+    constexpr int KHN = TAPS == 9 ? 3 : 1, NR = 4 + KHN - 1, NSTEP = KWN * NR;
+    bf16x8 A[KHN][4], B[2][2];
+    auto load_a = [&](int kw, int kh) {
+      const int tap = kh * 3 + kw;
 #pragma unroll
-    for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
+      for (int c4 = 0; c4 < 4; ++c4)
+        A[kh][c4] = *reinterpret_cast<const bf16x8*>(abase + so + tap * 4096 + c4 * 256);
+    };
+    auto load_b = [&](int st) {
+      const int kw = st / NR, rho = st % NR;
 #pragma unroll
-      for (int kw = 0; kw < (TAPS == 9 ? 3 : 1); ++kw) {
-        const int tap = kh * 3 + kw;
+      for (int hf = 0; hf < 2; ++hf)
+        B[st & 1][hf] = *reinterpret_cast<const bf16x8*>(bbase[kw][0] + so + rho * (G::HWd * G::PIXB) + hf * (16 * G::PIXB));
+    };
+    load_a(0, 0);
+    load_b(0);
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-          bf16x8 af[2], bfr[4];
+    for (int st = 0; st < NSTEP; ++st) {
+      const int kw = st / NR, rho = st % NR;
+      if (st + 1 < NSTEP) load_b(st + 1);
+      if (rho + 1 < KHN) load_a(kw, rho + 1);                 // first used by the next row
+      if (rho == NR - 1 && kw + 1 < KWN) load_a(kw + 1, 0);   // kh = 0 of this kw was last used at row 3
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2)
-            af[c2] = *reinterpret_cast<const bf16x8*>(abase + (tap * G::KS + ks) * 2048 + c2 * 512);
+      for (int kh = 0; kh < KHN; ++kh) {
+        const int p = rho - kh;
+        if (p < 0 || p > 3) continue;
 #pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            bfr[p] = *reinterpret_cast<const bf16x8*>(bbase[kw][ks] + (p + kh) * (G::HWd * G::PIXB));
-          }
+        for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-              acc[c2][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c2], bfr[p], acc[c2][p], 0, 0, 0);
-        }
+          for (int c4 = 0; c4 < 4; ++c4)
+            acc16[c4][2 * p + hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kh][c4], B[st & 1][hf], acc16[c4][2 * p + hf], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+  };
+  auto compute = [&](int so) {
+    if constexpr (M16) compute16(so); else compute32(so);
+  };
+
+  if (!DB) {
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+      stage(ch, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else {
+    stage(0, 0);
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+      const int so = (ch & 1) * STAGE;
+      if (ch + 1 < a.nchunks) {
+        stage(ch + 1, STAGE - so);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NLOAD_DB) : "memory");   // chunk ch has landed, ch+1 in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      compute(so);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // every wave is done reading this stage before it is refilled
+    }
   }
 
   // ---- epilogue: accumulators (+bias) -> bf16 tile in LDS.  D[row = out channel][col = pixel]:
   //      lane holds pixel r of its 32-pixel row and out channels (reg&3) + 8*(reg>>2) + 4*h.
   const int co0 = ct * 64;
   unsigned char* out_lds = smem;
+  if constexpr (M16) {   // lane holds column r of a 16-pixel half row and out channels c4*16 + 4*h + (0..3)
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const int cl = c4 * 16 + 4 * h;
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = (co0 + cl + e < a.Cout) ? a.bias[co0 + cl + e] : 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int q = (wave * 4 + (p >> 1)) * 32 + (p & 1) * 16 + r;
+        uint2 v;
+        v.x = pack_bf16x2(acc16[c4][p][0] + b4[0], acc16[c4][p][1] + b4[1]);
+        v.y = pack_bf16x2(acc16[c4][p][2] + b4[2], acc16[c4][p][3] + b4[3]);
+        *reinterpret_cast<uint2*>(out_lds + q * OUT_STRIDE + cl * 2) = v;
+      }
+    }
+  } else {
 #pragma unroll
   for (int c2 = 0; c2 < 2; ++c2) {
 #pragma unroll
@@ -201,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(FwdArgs a) {
         *reinterpret_cast<uint2*>(out_lds + q * OUT_STRIDE + cl * 2) = v;
       }
     }
+  }
   }
   __syncthreads();
 
@@ -311,7 +443,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int npairs = a.coTiles * a.ciTiles;
-  const int pair = blockIdx.x % npairs, split = blockIdx.x / npairs;
+  // XCD-aware order: the (out, in) tile pairs of one pixel slice run on the same XCD at about the same time, so the
+  // slice's x / dy tiles are fetched into that L2 once instead of once per pair
+  const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = bid % npairs, split = bid / npairs;
   const int cot = pair % a.coTiles, cit = pair / a.coTiles;
   const int ntiles = a.N * a.tilesY * a.tilesX;
   const int t_begin = split * a.tilesPerSplit;
@@ -434,6 +569,180 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// 3x3 wgrad over 64-wide in-channel tiles.  The generic kernel above reads one B fragment from LDS per MFMA, which
+// asks the LDS for its full 128 B/clk at the matrix pipe's peak rate.  Here a wave owns ALL 64 out channels (two A
+// fragments) x one 32-wide in-channel half x a group of 5 or 4 taps, so every B fragment feeds two MFMAs (7
+// fragment reads per 10 MFMAs instead of 10 per 9).  The 5/4 split alternates between co-resident workgroups so
+// the four SIMDs stay evenly loaded.  All LDS addresses are a per-lane base plus an immediate, and the fragments
+// of k-step s+1 are read while the MFMAs of step s run (two register sets).
+template <bool FIVE, bool BIAS>
+__device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* smem, int bid) {
+  using G = WgGeom<64, 9>;
+  constexpr int NT = FIVE ? 5 : 4, T0 = FIVE ? 0 : 5;
+  unsigned char* dy_lds = smem;
+  unsigned char* x_lds = smem + G::DY_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int npairs = a.coTiles * a.ciTiles;
+  const int pair = bid % npairs, split = bid / npairs;
+  const int cot = pair % a.coTiles, cit = pair / a.coTiles;
+  const int ntiles = a.N * a.tilesY * a.tilesX;
+  const int t_begin = split * a.tilesPerSplit;
+  const int t_end = t_begin + a.tilesPerSplit < ntiles ? t_begin + a.tilesPerSplit : ntiles;
+  const int ci_half = wave & 1;
+  const bool want_bias = BIAS && cit == 0;
+
+  f32x16 acc[NT][2];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+  float* b_lds = reinterpret_cast<float*>(smem + G::DY_BYTES + ((G::X_BYTES + 15) / 16) * 16);   // [4 waves][64 channels]
+  if (want_bias) b_lds[tid] = 0.f;   // ordered before its first use by the barrier that follows the first staging
+
+  // transposing-read lane geometry (see the generic kernel): lane -> (channel group of 4, pixel within the k-step)
+  const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
+  const int rb = (grp & 1) * 16, kb = (grp >> 1) * 8;
+  const int cb0 = kb + gq;   // this lane's first pixel column inside a 16-pixel k-step; the second is cb0 + 4
+  // dy tile: pixel p = row*32 + col; its chunk swizzle bit (p >> 1) & 1 only depends on cb0
+  const unsigned char* abase[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int ach = h * 32 + rb + 4 * gp;
+    abase[h] = dy_lds + cb0 * 128 + (((ach >> 3) ^ (((cb0 >> 1) & 1) << 2)) * 16) + (ach & 7) * 2;
+  }
+  // x halo: pixel q = (row + kh)*34 + col + kw; swizzle bit (q >> 1) & 1 = (((cb0 + kw) >> 1) + row + kh) & 1, so an
+  // odd tile row flips chunk bit 2 (byte-offset bit 6) relative to an even one
+  const unsigned char* bbase[NT][2];
+  {
+    const int bch = ci_half * 32 + rb + 4 * gp;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int kh = (T0 + i) / 3, kw = (T0 + i) % 3;
+      const int sw = ((((cb0 + kw) >> 1) + kh) & 1) << 2;
+      const int off = (kh * G::HWd + cb0 + kw) * 128 + (((bch >> 3) ^ sw) * 16) + (bch & 7) * 2;
+      bbase[i][0] = x_lds + off;
+      bbase[i][1] = x_lds + (off ^ 64);
+    }
+  }
+
+  for (int t = t_begin; t < t_end; ++t) {
+    int tt = t;
+    const int tx = tt % a.tilesX; tt /= a.tilesX;
+    const int ty = tt % a.tilesY;
+    const int n = tt / a.tilesY;
+    const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+#pragma unroll
+    for (int j = 0; j < G::JD; ++j) {
+      const int i = wave + 4 * j;
+      const int pix = i * 8 + (lane >> 3);
+      const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+      const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
+      const bool ok = gy < a.H && gx < a.W && cot * 64 + chunk * 8 < a.Cout;
+      const void* s = ok ? (const void*)(a.dy + (((int64_t)n * a.H + gy) * a.W + gx) * a.lddy + cot * 64 + chunk * 8)
+                         : (const void*)snws_zero_page;
+      glds16(s, dy_lds + i * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < G::JX; ++j) {
+      const int i = wave + 4 * j;
+      if (i < G::XNI) {
+        const int pix = i * 8 + (lane >> 3);
+        const int py = pix / G::HWd, px = pix - py * G::HWd;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
+        const bool ok = pix < G::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cit * 64 + chunk * 8 < a.Cin;
+        const void* s = ok ? (const void*)(a.x + (((int64_t)n * a.H + gy) * a.W + gx) * a.ldx + cit * 64 + chunk * 8)
+                           : (const void*)snws_zero_page;
+        glds16(s, x_lds + i * 1024);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (want_bias) {  // bias gradient: column sums of the dy tile, kept per wave in LDS (block-uniform branch)
+      const int c8 = tid & 7;
+      float bs[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pix = (tid >> 3) + 32 * j;
+        float f[8];
+        Vec<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(dy_lds + pix * 128 + ((c8 ^ (((pix >> 1) & 1) << 2)) * 16)), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] += f[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = bs[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 8) b_lds[wave * 64 + lane * 8 + e] += v;
+      }
+    }
+
+    // flat software pipeline over (k-step, tap): the B fragment of pair f+2 and the A fragments of the next k-step
+    // are read while the MFMAs of pair f run
+    bf16x8 af[2][2], bq[3];
+    auto load_a = [&](int ks) {
+      const int a_imm = ((ks >> 1) * 32 + (ks & 1) * 16) * 128;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) af[ks & 1][h] = tr_frag(abase[h] + a_imm, abase[h] + a_imm + 512);
+    };
+    auto load_b = [&](int f) {
+      const int ks = f / NT, i = f % NT, row = ks >> 1;
+      const int b_imm = (row * G::HWd + (ks & 1) * 16) * 128;
+      bq[f % 3] = tr_frag(bbase[i][row & 1] + b_imm, bbase[i][row & 1] + b_imm + 512);
+    };
+    load_a(0);
+    load_b(0);
+    load_b(1);
+#pragma unroll
+    for (int f = 0; f < 16 * NT; ++f) {
+      const int ks = f / NT, i = f % NT;
+      if (i == 0 && ks + 1 < 16) load_a(ks + 1);
+      if (f + 2 < 16 * NT) load_b(f + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][0], bq[f % 3], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][1], bq[f % 3], acc[i][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
+  const int ci = cit * 64 + ci_half * 32 + (lane & 31);
+  const bool ci_ok = ci < a.Cin;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * 64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ci_ok && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + (T0 + i)) * a.Cin + ci, acc[i][h][r]);
+      }
+    }
+  }
+  if (want_bias && tid < 64 && cot * 64 + tid < a.Cout)   // the loop's last barrier ordered every wave's partials
+    atomicAdd(a.dbias + cot * 64 + tid, b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192]);
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tg = __builtin_amdgcn_readfirstlane(((wave >> 1) ^ (bid >> 5)) & 1);
+  if (tg == 0) wgrad9_body<true, BIAS>(a, smem, bid);
+  else wgrad9_body<false, BIAS>(a, smem, bid);
+}
+
 // ------------------------------------------------------------------------------------------------- host
 int check_mfma_desc(const snws_conv_desc* d, const char* fn) {
   SNWS_CHECK_ARG(d, "%s: desc is NULL", fn);
@@ -452,22 +761,49 @@ int check_mfma_desc(const snws_conv_desc* d, const char* fn) {
   return SNWS_OK;
 }
 
-template <int KC, int TAPS>
-int launch_fwd(const FwdArgs& a, unsigned grid, hipStream_t st) {
+// SNWS_CONV_DB=0/1 overrides the default choice between the single- and double-buffered forward kernels
+int conv_db_mode() {
+  static int mode = -2;
+  if (mode == -2) {
+    const char* e = getenv("SNWS_CONV_DB");
+    mode = e ? atoi(e) : -1;
+  }
+  return mode;
+}
+
+template <int KC, int TAPS, bool DB, bool M16>
+int launch_fwd_v(const FwdArgs& a, unsigned grid, hipStream_t st) {
   using G = FwdGeom<KC, TAPS>;
+  constexpr int LDS = DB ? G::LDS_BYTES_DB : G::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<KC, TAPS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<KC, TAPS, DB, M16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SNWS_ERR_HIP;
     }
     attr_set = true;
   }
-  conv_fwd_kernel<KC, TAPS><<<grid, 256, G::LDS_BYTES, st>>>(a);
+  conv_fwd_kernel<KC, TAPS, DB, M16><<<grid, 256, LDS, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_fwd");
   return SNWS_OK;
+}
+
+// SNWS_CONV_DB = 0/1 forces the single- / double-buffered kernel, SNWS_CONV_M16 = 0/1 the MFMA shape; unset = the
+// measured best per shape
+template <int KC, int TAPS>
+int launch_fwd(const FwdArgs& a, unsigned grid, hipStream_t st) {
+  const int mode = conv_db_mode();
+  const bool db = (mode >= 0 ? mode == 1 : TAPS == 1) && a.nchunks >= 2;   // pays for 1x1 (short chunks), loses for 3x3
+  if constexpr (KC == 32) {
+    static const int m16_env = getenv("SNWS_CONV_M16") ? atoi(getenv("SNWS_CONV_M16")) : -1;
+    const bool m16 = m16_env >= 0 ? m16_env != 0 : true;   // +13% over 32x32x16 at equal cycles (higher sustained clock)
+    if (db) return m16 ? launch_fwd_v<32, TAPS, true, true>(a, grid, st) : launch_fwd_v<32, TAPS, true, false>(a, grid, st);
+    return m16 ? launch_fwd_v<32, TAPS, false, true>(a, grid, st) : launch_fwd_v<32, TAPS, false, false>(a, grid, st);
+  } else {
+    return launch_fwd_v<KC, TAPS, false, false>(a, grid, st);
+  }
 }
 
 // runs y(C_out_run channels) = conv(x(C_in_run channels), pack)
@@ -501,6 +837,24 @@ int launch_wgrad(const WgradArgs& a, unsigned grid, hipStream_t st) {
     attr_set = true;
   }
   conv_wgrad_kernel<CIC, TAPS><<<grid, 256, G::LDS_BYTES, st>>>(a);
+  SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
+  return SNWS_OK;
+}
+
+template <bool BIAS>
+int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
+  using G = WgGeom<64, 9>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9_kernel<BIAS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  conv_wgrad9_kernel<BIAS><<<grid, 256, G::LDS_BYTES, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
   return SNWS_OK;
 }
@@ -544,6 +898,11 @@ extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, cons
   const unsigned grid = (unsigned)(npairs * splits);
   const int taps = d->kh * d->kw;
   hipStream_t st = (hipStream_t)stream;
-  if (c64) return taps == 9 ? launch_wgrad<64, 9>(a, grid, st) : launch_wgrad<64, 1>(a, grid, st);
+  if (c64 && taps == 9) {
+    static const bool generic = getenv("SNWS_WGRAD_GENERIC") != nullptr;
+    if (generic) return launch_wgrad<64, 9>(a, grid, st);
+    return dbias ? launch_wgrad9<true>(a, grid, st) : launch_wgrad9<false>(a, grid, st);
+  }
+  if (c64) return launch_wgrad<64, 1>(a, grid, st);
   return taps == 9 ? launch_wgrad<16, 9>(a, grid, st) : launch_wgrad<16, 1>(a, grid, st);
 }
