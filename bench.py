@@ -92,12 +92,15 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--filters", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="unet3p", choices=["unet3p", "unet3p_res_ocr"],
+                    help="unet3p = the headline UNet3p_SNws; unet3p_res_ocr = UNet3p_res_ocr_SNws (residual encoder + OCR head)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
     from snws import harness, ops
     from modeling.UNet3p_SNws import UNet3p_SNws
+    from modeling.UNet3p_res_ocr_SNws import UNet3p_res_ocr_SNws
 
     rank, world, device = harness.init_distributed()
     if not torch.cuda.is_available():
@@ -106,7 +109,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
 
     torch.manual_seed(1)
-    model = UNet3p_SNws(14, args.filters, 10, 1, 1).to(device)
+    cls = UNet3p_SNws if args.model == "unet3p" else UNet3p_res_ocr_SNws
+    model = cls(14, args.filters, 10, 1, 1).to(device)
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if world > 1:   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
@@ -164,18 +168,18 @@ def main():
                 summary[tag] = {"launches": cnt, "ms_per_step": tt / args.steps * 1e3, "GB/s": work / tt / 1e9,
                                 "frac_of_hbm_peak": work / tt / 1e9 / HBM_PEAK_GBS}
         out = {
-            "metric": "train images/sec (node) UNet3p_SNws 512x512", "value": args.batch * world * args.steps / elapsed,
+            "metric": "train images/sec (node) %s 512x512" % cls.__name__, "value": args.batch * world * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "UNet3p_SNws(n_channels=14, n_filters=%d, n_class=10) training step, "
+            "config": {"workload": "%s(n_channels=14, n_filters=%d, n_class=10) training step, "
                                    "%dx%d synthetic 14-band tiles, batch %d per GPU, AdamW + poly LR, CE/N loss"
-                                   % (args.filters, args.size, args.size, args.batch),
+                                   % (cls.__name__, args.filters, args.size, args.size, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "loss": loss_val, "roofline": roofline, "kernels": summary,
         }
         out["evaluator"] = evaluator_throughput(device)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "unet3p":
             out["cpu_baseline"] = cpu_baseline(args.filters, args.size)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -407,6 +407,12 @@ class OracleNet:
         d3 = c('convd3_2', c('convd3_1', mp(d2, 2)))
         d4 = c('convd4_2', c('convd4_1', mp(d3, 2)))
         c5 = c('conv5_2', c('conv5_1', mp(d4, 2)))
+        return self.head(self.full_scale_decoder(d1, d2, d3, d4, c5))
+
+    def full_scale_decoder(self, d1, d2, d3, d4, c5):
+        """UNet3p_SNws.py:127-156 (the same lines as UNet3p_res_ocr_SNws.py:327-361)."""
+        c, mp = self.csr, maxpool_ceil
+        up = lambda t, k: self.rnd(upsample_bilinear(t, k))  # noqa: E731
         u4 = c('conv_fusion', torch.cat((c('convd1_cat', mp(d1, 8)), c('convd2_cat', mp(d2, 4)),
                                          c('convd3_cat', mp(d3, 2)), c('convd4_cat', d4),
                                          c('conv5_cat', up(c5, 2))), 1))
@@ -419,7 +425,77 @@ class OracleNet:
         u1 = c('conv_fusion', torch.cat((c('convd1_cat', d1), c('convu_cat', up(u2, 2)),
                                          c('convu_cat', up(u3, 4)), c('convu_cat', up(u4, 8)),
                                          c('conv5_cat', up(c5, 16))), 1))
-        return self.head(u1)
+        return u1
+
+    # ---- UNet3p_res_ocr_SNws (UNet3p_res_ocr_SNws.py:211-377)
+    def _sn(self, y, prefix, relu):
+        p = self.p
+        st = SNState.__new__(SNState)
+        st.C, st.eps, st.momentum = y.shape[1], 1e-5, 0.997
+        st.using_movavg, st.using_bn = self.using_movavg, self.using_bn
+        st.gamma, st.beta = p[prefix + '.weight'].reshape(-1), p[prefix + '.bias'].reshape(-1)
+        st.mean_weight, st.var_weight = p[prefix + '.mean_weight'], p[prefix + '.var_weight']
+        st.running_mean, st.running_var = p[prefix + '.running_mean'].view(-1), p[prefix + '.running_var'].view(-1)
+        out, _ = switchnorm_fwd(y, st, self.training, self.allreduce, relu=relu)
+        return out
+
+    def basic(self, name, x):
+        """Resnet_BasicBlock with downsample=None (UNet3p_res_ocr_SNws.py:134-161): conv1-bn1-relu-conv2-bn2,
+        += the block input, relu."""
+        p = self.p
+        y = self.rnd(F.conv2d(x, self.rnd(ws_standardize(p[name + '.conv1.weight'])), p[name + '.conv1.bias'], 1, 1))
+        y = self.rnd(self._sn(y, name + '.bn1', True))
+        y = self.rnd(F.conv2d(y, self.rnd(ws_standardize(p[name + '.conv2.weight'])), p[name + '.conv2.bias'], 1, 1))
+        return self.rnd(torch.relu(self._sn(y, name + '.bn2', False) + x))
+
+    def conv_plain(self, name, x):
+        w = self.p[name + '.weight']
+        b = self.p.get(name + '.bias')
+        return self.rnd(F.conv2d(x, self.rnd(w), b, 1, (w.shape[2] - 1) // 2))
+
+    def bn_relu(self, name, x):
+        """nn.BatchNorm2d (batch statistics of THIS process, momentum 0.1) + ReLU."""
+        p = self.p
+        y = F.batch_norm(x, p[name + '.running_mean'], p[name + '.running_var'], p[name + '.weight'], p[name + '.bias'],
+                         self.training, 0.1, 1e-5)
+        if self.training:
+            p[name + '.num_batches_tracked'] += 1
+        return self.rnd(torch.relu(y))
+
+    def cbr(self, seq, x, i=0):
+        """Sequential(..., i: Conv2d, i+1: BatchNorm2d, i+2: ReLU, ...)."""
+        return self.bn_relu('%s.%d' % (seq, i + 1), self.conv_plain('%s.%d' % (seq, i), x))
+
+    def ocr_head(self, u1):
+        """UNet3p_res_ocr_SNws.py:363-371 with SpatialGather_Module :21-28, _ObjectAttentionBlock :82-104 (scale 1)
+        and SpatialOCR_Module :129-132 (Dropout2d taken as identity: p = 0 or eval mode)."""
+        B = u1.shape[0]
+        out_aux = self.conv_plain('aux_head.3', self.cbr('aux_head', u1))
+        feats = self.cbr('conv3x3_ocr', u1)
+        C, H, W = feats.shape[1:]
+        probs = self.rnd(torch.softmax(out_aux.reshape(B, out_aux.shape[1], -1), dim=2))       # B x K x HW
+        proxy = self.rnd(torch.matmul(probs, feats.reshape(B, C, -1).permute(0, 2, 1)))        # B x K x C
+        proxy = proxy.permute(0, 2, 1).unsqueeze(3)                                            # B x C x K x 1
+        blk = 'ocr_distri_head.object_context_block.'
+        kc = self.p[blk + 'f_pixel.0.weight'].shape[0]
+        query = self.cbr(blk + 'f_pixel', self.cbr(blk + 'f_pixel', feats), 3).reshape(B, kc, -1).permute(0, 2, 1)
+        key = self.cbr(blk + 'f_object', self.cbr(blk + 'f_object', proxy), 3).reshape(B, kc, -1)
+        value = self.cbr(blk + 'f_down', proxy).reshape(B, kc, -1).permute(0, 2, 1)
+        sim = self.rnd(torch.softmax(torch.matmul(query, key) * kc ** -0.5, dim=-1))           # B x HW x K
+        ctx = self.rnd(torch.matmul(sim, value)).permute(0, 2, 1).reshape(B, kc, H, W)
+        ctx = self.cbr(blk + 'f_up', ctx)
+        feats = self.cbr('ocr_distri_head.conv_bn_dropout', torch.cat([ctx, feats], 1))
+        return self.conv_plain('cls_head', feats)
+
+    def unet3p_res_ocr(self, x):
+        c, mp, rb = self.csr, maxpool_ceil, self.basic
+        up = lambda t, k: self.rnd(upsample_bilinear(t, k))  # noqa: E731
+        d1 = rb('convd1_2', c('convd1_1', x))
+        d2 = rb('convd2_2', c('convd2_1', mp(d1, 2)))
+        d3 = rb('convd3_2', c('convd3_1', mp(d2, 2)))
+        d4 = rb('convd4_2', c('convd4_1', mp(d3, 2)))
+        c5 = rb('conv5_2', c('conv5_1', mp(d4, 2)))
+        return self.ocr_head(self.full_scale_decoder(d1, d2, d3, d4, c5))
 
     def unet(self, x):
         """UNet_SNws.py:95-152."""
@@ -464,6 +540,8 @@ def make_state(arch, n_channels, n_filters, n_class, dtype=torch.float32):
     elif arch == 'unet':
         blocks = UNET_BLOCKS
         head_in = n_filters
+    elif arch == 'unet3p_res_ocr':
+        return _make_state_res_ocr(n_channels, n_filters, n_class, dtype)
     else:
         raise ValueError(arch)
     for name, ci, co, k in blocks:
@@ -482,8 +560,70 @@ def make_state(arch, n_channels, n_filters, n_class, dtype=torch.float32):
     return st
 
 
+def _sn_entries(st, prefix, c, dtype):
+    st[prefix + '.weight'] = torch.ones(1, c, 1, 1, dtype=dtype)
+    st[prefix + '.bias'] = torch.zeros(1, c, 1, 1, dtype=dtype)
+    st[prefix + '.mean_weight'] = torch.ones(3, dtype=dtype)
+    st[prefix + '.var_weight'] = torch.ones(3, dtype=dtype)
+    st[prefix + '.running_mean'] = torch.zeros(1, c, 1, dtype=dtype)
+    st[prefix + '.running_var'] = torch.zeros(1, c, 1, dtype=dtype)
+
+
+def _bn_entries(st, prefix, c, dtype):
+    st[prefix + '.weight'] = torch.ones(c, dtype=dtype)
+    st[prefix + '.bias'] = torch.zeros(c, dtype=dtype)
+    st[prefix + '.running_mean'] = torch.zeros(c, dtype=dtype)
+    st[prefix + '.running_var'] = torch.ones(c, dtype=dtype)
+    st[prefix + '.num_batches_tracked'] = torch.zeros((), dtype=torch.int64)
+
+
+def _make_state_res_ocr(n_channels, f, n_class, dtype):
+    """state_dict of UNet3p_res_ocr_SNws in the reference's registration order (UNet3p_res_ocr_SNws.py:226-294)."""
+    st = {}
+
+    def csr(name, cin, cout):
+        st[name + '.0.weight'] = torch.zeros(cout, cin, 3, 3, dtype=dtype)
+        st[name + '.0.bias'] = torch.zeros(cout, dtype=dtype)
+        _sn_entries(st, name + '.1', cout, dtype)
+
+    def basic(name, c):
+        for i in ('1', '2'):
+            st[name + '.conv' + i + '.weight'] = torch.zeros(c, c, 3, 3, dtype=dtype)
+            st[name + '.conv' + i + '.bias'] = torch.zeros(c, dtype=dtype)
+            _sn_entries(st, name + '.bn' + i, c, dtype)
+
+    def conv(name, cin, cout, k, bias):
+        st[name + '.weight'] = torch.zeros(cout, cin, k, k, dtype=dtype)
+        if bias:
+            st[name + '.bias'] = torch.zeros(cout, dtype=dtype)
+
+    widths = [n_channels, f, 2 * f, 4 * f, 8 * f, 16 * f]
+    for i, name in enumerate(['convd1', 'convd2', 'convd3', 'convd4', 'conv5']):
+        csr(name + '_1', widths[i], widths[i + 1])
+        basic(name + '_2', widths[i + 1])
+    mid, key = 512, 256
+    conv('aux_head.0', 5 * f, 5 * f, 1, True); _bn_entries(st, 'aux_head.1', 5 * f, dtype)
+    conv('aux_head.3', 5 * f, n_class, 1, True)
+    conv('conv3x3_ocr.0', 5 * f, mid, 3, True); _bn_entries(st, 'conv3x3_ocr.1', mid, dtype)
+    blk = 'ocr_distri_head.object_context_block.'
+    for branch in ('f_pixel', 'f_object'):
+        conv(blk + branch + '.0', mid, key, 1, False); _bn_entries(st, blk + branch + '.1', key, dtype)
+        conv(blk + branch + '.3', key, key, 1, False); _bn_entries(st, blk + branch + '.4', key, dtype)
+    conv(blk + 'f_down.0', mid, key, 1, False); _bn_entries(st, blk + 'f_down.1', key, dtype)
+    conv(blk + 'f_up.0', key, mid, 1, False); _bn_entries(st, blk + 'f_up.1', mid, dtype)
+    conv('ocr_distri_head.conv_bn_dropout.0', 2 * mid, mid, 1, False)
+    _bn_entries(st, 'ocr_distri_head.conv_bn_dropout.1', mid, dtype)
+    conv('cls_head', mid, n_class, 1, True)
+    for name, cin in (('convd1_cat', f), ('convd2_cat', 2 * f), ('convd3_cat', 4 * f), ('convd4_cat', 8 * f),
+                      ('conv5_cat', 16 * f), ('convu_cat', 5 * f)):
+        csr(name, cin, f)
+    csr('conv_fusion', 5 * f, 5 * f)
+    conv('output_seg_map', f, n_class, 1, True)     # registered but unused by forward (:294)
+    return st
+
+
 def is_buffer(key):
-    return key.endswith('running_mean') or key.endswith('running_var')
+    return key.endswith('running_mean') or key.endswith('running_var') or key.endswith('num_batches_tracked')
 
 
 def model_step(arch, state, img, target, training=True, allreduce=None, loss_div=None, act_round=None):
@@ -491,12 +631,12 @@ def model_step(arch, state, img, target, training=True, allreduce=None, loss_div
     params = {k: (v if is_buffer(k) else v.detach().clone().requires_grad_(training)) for k, v in state.items()}
     net = OracleNet(params, allreduce=allreduce, act_round=act_round)
     net.training = training
-    logits = net.unet3p(img) if arch == 'unet3p' else net.unet(img)
+    logits = {'unet3p': net.unet3p, 'unet': net.unet, 'unet3p_res_ocr': net.unet3p_res_ocr}[arch](img)
     loss = ce_loss_batch_avg(logits, target)
     if loss_div is not None:
         loss = loss * (logits.shape[0] / loss_div)
     grads = {}
     if training:
         loss.backward()
-        grads = {k: v.grad for k, v in params.items() if not is_buffer(k)}
+        grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in params.items() if not is_buffer(k)}
     return logits.detach(), float(loss.detach()), grads

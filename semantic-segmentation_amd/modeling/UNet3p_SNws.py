@@ -7,7 +7,7 @@ The seven decoder blocks are shared by the four decoder scales, as in the refere
 import torch
 import torch.nn as nn
 
-from modeling.blocks import ConvSnRelu, head_conv, to_device_layout
+from modeling.blocks import ConvSnRelu, full_scale_decoder, head_conv, to_device_layout
 from snws import ops
 
 
@@ -41,29 +41,4 @@ class UNet3p_SNws(nn.Module):
                 t = ops.max_pool_ceil(t, 2)
             t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
             enc[lvl] = t
-        enc_cat = {1: self.convd1_cat, 2: self.convd2_cat, 3: self.convd3_cat, 4: self.convd4_cat}
-        # Every up-sampled source goes through conv(upsample(x)) = sum_t up(W_t x): the 1x1 half Z = W_taps x is
-        # computed once per source at ITS resolution and shared by all the scales that consume it.
-        z5 = self.conv5_cat.taps(enc[5])
-        zdec = {}
-        dec = {}
-        f = self.Cat_channels
-        for level in (4, 3, 2, 1):
-            # the five 64-channel blocks write straight into their channel slice of the fusion input: no torch.cat
-            ref = enc[level]
-            buf = ops.new_nhwc(ref.shape[0], 5 * f, ref.shape[2], ref.shape[3], ref.dtype, ref.device)
-            parts = []
-            for src in (1, 2, 3, 4):
-                out = buf[:, len(parts) * f:(len(parts) + 1) * f]
-                if src < level:         # encoder map, max-pooled down to this level
-                    parts.append(enc_cat[src](ops.max_pool_ceil(enc[src], 2 ** (level - src)), out=out))
-                elif src == level:
-                    parts.append(enc_cat[src](enc[src], out=out))
-                else:                   # decoder map of a coarser level, up-sampled
-                    if src not in zdec:
-                        zdec[src] = self.convu_cat.taps(dec[src])
-                    parts.append(self.convu_cat.up(zdec[src], 2 ** (src - level), out=out))
-            # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
-            parts.append(self.conv5_cat.up(z5, 2 ** (5 - level), out=buf[:, 4 * f:5 * f]))
-            dec[level] = self.conv_fusion(ops.AssembleFn.apply(buf, *parts))
-        return head_conv(self.output_seg_map, dec[1])
+        return head_conv(self.output_seg_map, full_scale_decoder(self, enc))

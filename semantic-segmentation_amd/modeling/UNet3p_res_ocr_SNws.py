@@ -1,0 +1,179 @@
+"""UNet3+ with residual encoder blocks and an OCR (object-contextual representation) head - the build's counterpart
+of the reference's modeling/UNet3p_res_ocr_SNws.py:10-377: same class names, constructors, parameter / buffer names,
+shapes and registration order (a reference checkpoint loads with load_state_dict), same arithmetic.
+
+What runs where: every Conv2dws -> SwitchNorm2d -> ReLU block, the residual blocks' conv + SwitchNorm + add + ReLU,
+the full-scale skip decoder and all plain nn.Conv2d layers (1x1 and the 320 -> 512 3x3) go through the library's
+HIP kernels.  The OCR head's BatchNorm2d layers, its two soft-max + batched-matmul attention steps and Dropout2d are
+stock torch ops on the GPU (rocBLAS / elementwise), as plain library work.  BatchNorm2d uses the statistics of the
+local batch, as under the reference's DataParallel.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.conv import _ConvNd
+from torch.nn.modules.utils import _pair
+
+import modeling.snorm as sn
+import modeling.weightstd as ws
+from modeling.blocks import (ConvSnRelu, PlainConv2d, Resnet_BasicBlock, crop_concat as CropConcat,  # noqa: F401
+                             full_scale_decoder, head_conv, plain_conv, to_device_layout)
+from snws import ops
+
+
+def _pixels(x):
+    """(B,C,H,W) channels-last -> (B, H*W, C) without a copy."""
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+
+
+class SpatialGather_Module(nn.Module):
+    """Soft object regions: class-probability-weighted average of the pixel features
+    (modeling/UNet3p_res_ocr_SNws.py:10-28).  The soft-max over pixels runs in float32."""
+
+    def __init__(self, cls_num=0, scale=1):
+        super(SpatialGather_Module, self).__init__()
+        self.cls_num = cls_num
+        self.scale = scale
+
+    def forward(self, feats, probs):
+        B, K = probs.size(0), probs.size(1)
+        p = F.softmax(self.scale * probs.float().reshape(B, K, -1), dim=2)              # B x K x HW
+        ctx = torch.matmul(p.to(feats.dtype), _pixels(feats))                           # B x K x C
+        return ctx.permute(0, 2, 1).unsqueeze(3)                                        # B x C x K x 1
+
+
+class _ObjectAttentionBlock(nn.Module):
+    """Pixel-to-object-region attention (modeling/UNet3p_res_ocr_SNws.py:31-104)."""
+
+    def __init__(self, in_channels, key_channels, scale=1):
+        super(_ObjectAttentionBlock, self).__init__()
+        self.scale = scale
+        self.in_channels = in_channels
+        self.key_channels = key_channels
+        self.pool = nn.MaxPool2d(kernel_size=(scale, scale))
+
+        def cbr(cin, cout):
+            return [PlainConv2d(cin, cout, kernel_size=1, stride=1, padding=0, bias=False), nn.BatchNorm2d(cout), nn.ReLU()]
+        self.f_pixel = nn.Sequential(*(cbr(in_channels, key_channels) + cbr(key_channels, key_channels)))
+        self.f_object = nn.Sequential(*(cbr(in_channels, key_channels) + cbr(key_channels, key_channels)))
+        self.f_down = nn.Sequential(*cbr(in_channels, key_channels))
+        self.f_up = nn.Sequential(*cbr(key_channels, in_channels))
+
+    def forward(self, x, proxy):
+        B, h, w = x.size(0), x.size(2), x.size(3)
+        if self.scale > 1:
+            x = self.pool(x)
+        proxy = proxy.contiguous(memory_format=torch.channels_last)
+        query = _pixels(self.f_pixel(x))                                                 # B x HW x key
+        key = self.f_object(proxy).reshape(B, self.key_channels, -1)                     # B x key x K
+        value = _pixels(self.f_down(proxy))                                              # B x K x key
+        # attention logits in float32: a bf16 result would carry ~0.4 % of |logit| into the soft-max exponent
+        sim = torch.matmul(query.float(), key.float()) * (self.key_channels ** -.5)
+        sim = F.softmax(sim, dim=-1).to(query.dtype)                                     # B x HW x K
+        context = torch.matmul(sim, value)                                               # B x HW x key
+        context = context.reshape(B, x.size(2), x.size(3), self.key_channels).permute(0, 3, 1, 2)
+        context = self.f_up(context)
+        if self.scale > 1:
+            context = F.interpolate(input=context, size=(h, w), mode='bilinear', align_corners=True)
+        return context
+
+
+class ObjectAttentionBlock2D(_ObjectAttentionBlock):
+    def __init__(self, in_channels, key_channels, scale=1):
+        super(ObjectAttentionBlock2D, self).__init__(in_channels, key_channels, scale)
+
+
+class SpatialOCR_Module(nn.Module):
+    """Object context + pixel features -> 1x1 conv, BN, ReLU, Dropout2d (modeling/UNet3p_res_ocr_SNws.py:112-132)."""
+
+    def __init__(self, in_channels, key_channels, out_channels, scale=1, dropout=0.1):
+        super(SpatialOCR_Module, self).__init__()
+        self.object_context_block = ObjectAttentionBlock2D(in_channels, key_channels, scale)
+        self.conv_bn_dropout = nn.Sequential(
+            PlainConv2d(2 * in_channels, out_channels, kernel_size=1, padding=0, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(),
+            nn.Dropout2d(dropout))
+
+    def forward(self, feats, proxy_feats):
+        context = self.object_context_block(feats, proxy_feats)
+        return self.conv_bn_dropout(torch.cat([context, feats], 1))
+
+
+class GatedSpatialConv2d(_ConvNd):
+    """Gated convolution of modeling/UNet3p_res_ocr_SNws.py:163-196 (defined by the reference, not used by its
+    model).  The gate runs on the library's SwitchNorm / Conv2dws ops; the final convolution is a stride-1 'same'
+    convolution through plain_conv."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, dilation=1, groups=1, bias=False):
+        super(GatedSpatialConv2d, self).__init__(in_channels, out_channels, _pair(kernel_size), _pair(stride),
+                                                 _pair(padding), _pair(dilation), False, _pair(0), groups, bias, 'zeros')
+        self.gate_conv = nn.Sequential(
+            sn.SwitchNorm2d(in_channels + 1),
+            ws.Conv2dws(in_channels + 1, in_channels + 1, 1),
+            nn.ReLU(),
+            ws.Conv2dws(in_channels + 1, 1, 1),
+            sn.SwitchNorm2d(1),
+            nn.Sigmoid())
+
+    def forward(self, input_features, gating_features):
+        alphas = self.gate_conv(torch.cat([input_features, gating_features], dim=1))
+        return plain_conv(self, input_features * (alphas + 1))
+
+    def reset_parameters(self):
+        nn.init.xavier_normal_(self.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+
+class UNet3p_res_ocr_SNws(nn.Module):
+    def __init__(self, n_channels, n_filters, n_class, using_movavg, using_bn):
+        super(UNet3p_res_ocr_SNws, self).__init__()
+        f = n_filters
+        kw = dict(using_movavg=using_movavg, using_bn=using_bn)
+        widths = [n_channels, f, 2 * f, 4 * f, 8 * f, 16 * f]
+        for i, name in enumerate(['convd1', 'convd2', 'convd3', 'convd4', 'conv5']):
+            setattr(self, name + '_1', ConvSnRelu(widths[i], widths[i + 1], **kw))
+            setattr(self, name + '_2', Resnet_BasicBlock(widths[i + 1], widths[i + 1], stride=1, downsample=None))
+
+        ocr_mid_channels = 512
+        ocr_key_channels = 256
+        self.aux_head = nn.Sequential(
+            PlainConv2d(5 * f, 5 * f, kernel_size=1, stride=1, padding=0),
+            nn.BatchNorm2d(5 * f),
+            nn.ReLU(inplace=True),
+            PlainConv2d(5 * f, n_class, kernel_size=1, stride=1, padding=0, bias=True))
+        self.conv3x3_ocr = nn.Sequential(
+            PlainConv2d(5 * f, ocr_mid_channels, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(ocr_mid_channels),
+            nn.ReLU(inplace=True))
+        self.ocr_gather_head = SpatialGather_Module(n_class)
+        self.ocr_distri_head = SpatialOCR_Module(in_channels=ocr_mid_channels, key_channels=ocr_key_channels,
+                                                 out_channels=ocr_mid_channels, scale=1, dropout=0.05)
+        self.cls_head = nn.Conv2d(ocr_mid_channels, n_class, kernel_size=1, stride=1, padding=0, bias=True)
+
+        self.Cat_channels = f
+        self.Fusion_channels = 5 * f
+        for name, cin in (('convd1_cat', f), ('convd2_cat', 2 * f), ('convd3_cat', 4 * f), ('convd4_cat', 8 * f),
+                          ('conv5_cat', 16 * f), ('convu_cat', 5 * f)):
+            setattr(self, name, ConvSnRelu(cin, f, **kw))
+        self.conv_fusion = ConvSnRelu(5 * f, 5 * f, **kw)
+        self.output_seg_map = nn.Conv2d(f, n_class, kernel_size=1, stride=1, padding=0)   # registered, unused (:294)
+        self.compute_dtype = None      # None: keep the input's dtype; torch.bfloat16 for the MFMA tier
+
+    def forward(self, x):
+        x = to_device_layout(x, self.compute_dtype)
+        enc = {}
+        t = x
+        for lvl, name in enumerate(['convd1', 'convd2', 'convd3', 'convd4', 'conv5'], start=1):
+            if lvl > 1:
+                t = ops.max_pool_ceil(t, 2)
+            t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
+            enc[lvl] = t
+        convu1 = full_scale_decoder(self, enc)
+        out_aux = self.aux_head(convu1)
+        feats = self.conv3x3_ocr(convu1)
+        context = self.ocr_gather_head(feats, out_aux)
+        feats = self.ocr_distri_head(feats, context)
+        return head_conv(self.cls_head, feats)

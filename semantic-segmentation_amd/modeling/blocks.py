@@ -74,19 +74,91 @@ def to_device_layout(x, dtype=None):
     return x.contiguous(memory_format=torch.channels_last)
 
 
-def head_conv(conv, x):
-    """The plain nn.Conv2d 1x1 classification head (modeling/UNet3p_SNws.py:93,158) through the library's own conv
-    kernels; returns float32 logits.  For bf16 activations the filter is zero-padded to a multiple of 16 output
-    channels so the MFMA kernels take it; the padding is sliced off again (autograd sees plain pad/slice ops)."""
-    ops.require_gpu(x, "classification head")
+def plain_conv(conv, x):
+    """A plain (not standardized) stride-1 'same' nn.Conv2d through the library's own conv kernels, in x's dtype.
+    For bf16 activations the filter is zero-padded to a multiple of 16 output channels so the MFMA kernels take
+    it; the padding is sliced off again (autograd sees plain pad/slice ops)."""
+    ops.require_gpu(x, "nn.Conv2d")
     w, b = conv.weight, conv.bias
     n_out = w.shape[0]
     if conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or \
             tuple(conv.padding) != ((w.shape[2] - 1) // 2, (w.shape[3] - 1) // 2):
-        raise NotImplementedError("head_conv handles stride-1 'same' convolutions")
+        raise NotImplementedError("plain_conv handles stride-1 'same' convolutions")
     pad = (-n_out) % 16 if x.dtype == torch.bfloat16 else 0
     if pad:
         w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, pad))
         b = None if b is None else torch.nn.functional.pad(b, (0, pad))
     y = ops.PlainConvFn.apply(x, w, b)
-    return y[:, :n_out].float()
+    return y[:, :n_out] if pad else y
+
+
+def head_conv(conv, x):
+    """The plain nn.Conv2d 1x1 classification head (modeling/UNet3p_SNws.py:93,158); returns float32 logits."""
+    return plain_conv(conv, x).float()
+
+
+class PlainConv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters, same state_dict keys) whose forward runs the library's conv kernels."""
+
+    def forward(self, x):
+        return plain_conv(self, x)
+
+
+class Resnet_BasicBlock(nn.Module):
+    """conv1-bn1-relu-conv2-bn2, += block input, relu (modeling/UNet3p_res_ocr_SNws.py:134-161) as two fused ops:
+    ConvSnRelu and conv + SwitchNorm + residual add + ReLU."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super(Resnet_BasicBlock, self).__init__()
+        self.conv1 = ws.Conv2dws(inplanes, planes, kernel_size=3, stride=1, padding=1)
+        self.bn1 = sn.SwitchNorm2d(planes)
+        self.conv2 = ws.Conv2dws(planes, planes, kernel_size=3, stride=1, padding=1)
+        self.bn2 = sn.SwitchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        ops.require_gpu(x, "Resnet_BasicBlock")
+        mf = x.dtype == torch.bfloat16
+        c1, n1, c2, n2 = self.conv1, self.bn1, self.conv2, self.bn2
+        t = ops.ConvSnReluFn.apply(x, c1.weight, c1.bias, n1.weight, n1.bias, n1.mean_weight, n1.var_weight,
+                                   c1.prepared(mf and not c1.force_direct), ops.SNParams(n1), True, None)
+        if self.downsample is not None:
+            # the reference feeds conv2's OUTPUT to downsample (:156); kept, unfused
+            y = ops.Conv2dwsFn.apply(t, c2.weight, c2.bias, c2.prepared(mf and not c2.force_direct), c2.force_direct)
+            out = ops.SwitchNormFn.apply(y, n2.weight, n2.bias, n2.mean_weight, n2.var_weight, ops.SNParams(n2), False)
+            return torch.relu(out + self.downsample(y))
+        return ops.ConvSnAddReluFn.apply(t, c2.weight, c2.bias, n2.weight, n2.bias, n2.mean_weight, n2.var_weight,
+                                         c2.prepared(mf and not c2.force_direct), ops.SNParams(n2), x)
+
+
+def full_scale_decoder(m, enc):
+    """The UNet3+ full-scale skip decoder (modeling/UNet3p_SNws.py:127-156, UNet3p_res_ocr_SNws.py:327-361) over
+    the encoder maps enc[1..5]; m holds convd{1..4}_cat, conv5_cat, convu_cat, conv_fusion.  Returns the finest
+    decoder map.  Every up-sampled source goes through conv(upsample(x)) = sum_t up(W_t x): the 1x1 half
+    Z = W_taps x is computed once per source at ITS resolution and shared by all the scales that consume it."""
+    enc_cat = {1: m.convd1_cat, 2: m.convd2_cat, 3: m.convd3_cat, 4: m.convd4_cat}
+    z5 = m.conv5_cat.taps(enc[5])
+    zdec = {}
+    dec = {}
+    f = m.Cat_channels
+    for level in (4, 3, 2, 1):
+        # the five 64-channel blocks write straight into their channel slice of the fusion input: no torch.cat
+        ref = enc[level]
+        buf = ops.new_nhwc(ref.shape[0], 5 * f, ref.shape[2], ref.shape[3], ref.dtype, ref.device)
+        parts = []
+        for src in (1, 2, 3, 4):
+            out = buf[:, len(parts) * f:(len(parts) + 1) * f]
+            if src < level:         # encoder map, max-pooled down to this level
+                parts.append(enc_cat[src](ops.max_pool_ceil(enc[src], 2 ** (level - src)), out=out))
+            elif src == level:
+                parts.append(enc_cat[src](enc[src], out=out))
+            else:                   # decoder map of a coarser level, up-sampled
+                if src not in zdec:
+                    zdec[src] = m.convu_cat.taps(dec[src])
+                parts.append(m.convu_cat.up(zdec[src], 2 ** (src - level), out=out))
+        # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
+        parts.append(m.conv5_cat.up(z5, 2 ** (5 - level), out=buf[:, 4 * f:5 * f]))
+        dec[level] = m.conv_fusion(ops.AssembleFn.apply(buf, *parts))
+    return dec[1]

@@ -485,6 +485,42 @@ class ConvSnReluFn(torch.autograd.Function):
         return dx, dw, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None, None
 
 
+class ConvSnAddReluFn(torch.autograd.Function):
+    """relu(SwitchNorm2d(Conv2dws(x)) + residual): the second half of Resnet_BasicBlock
+    (modeling/UNet3p_res_ocr_SNws.py:152-159) as one fused op.  The residual add and the ReLU run in the
+    SwitchNorm apply kernel; backward takes the ReLU mask from the saved block output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, mean_weight, var_weight, prep, p, residual):
+        conv_out, stat, saved = conv_forward(x, prep, bias, want_stats=True)
+        shift = None
+        if stat is not None:
+            shift = _f32c(bias) if bias is not None else torch.zeros(weight.shape[0], dtype=torch.float32,
+                                                                       device=x.device)
+        y, sn_saved = sn_forward(conv_out, p, True, stat_part=stat, stat_shift=shift, residual=residual)
+        ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
+        ctx.shapes = (gamma.shape, beta.shape)
+        ctx.res_dtype = residual.dtype
+        ctx.save_for_backward(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        y = ctx.sn["y"]
+        dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn)
+        dres = None
+        if ctx.needs_input_grad[9]:
+            dres = torch.where(y > 0, dy.to(y.dtype), torch.zeros((), dtype=y.dtype, device=y.device)).to(ctx.res_dtype)
+        ctx.sn = None
+        nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb)
+        ctx.saved = None
+        if dw is not None:
+            dw = dw.to(weight.dtype)
+        return dx, dw, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, dres
+
+
 # ------------------------------------------------------------------------------------------------ conv of an up-sampled map
 class PreparedTaps:
     """The standardized filter of a Conv2dws re-laid as a 1x1 filter with taps*O output channels (tap-major):

@@ -17,6 +17,7 @@ Reference entry points exercised (file:line in /root/reference):
   modeling/snorm.py:5-81          SwitchNorm2d
   modeling/UNet_SNws.py:42-152    UNet_SNws
   modeling/UNet3p_SNws.py:42-160  UNet3p_SNws
+  modeling/UNet3p_res_ocr_SNws.py:211-377  UNet3p_res_ocr_SNws (Dropout2d p set to 0: it is RNG-dependent)
   utils/metrics.py:4-52           Evaluator
   utils/loss.py:146-159           SegmentationLosses.CrossEntropyLoss
   utils/lr_scheduler.py:43-61     LR_Scheduler (poly)
@@ -39,6 +40,7 @@ import modeling.weightstd as ref_ws            # noqa: E402
 import modeling.snorm as ref_sn                # noqa: E402
 from modeling.UNet_SNws import UNet_SNws       # noqa: E402
 from modeling.UNet3p_SNws import UNet3p_SNws   # noqa: E402
+from modeling.UNet3p_res_ocr_SNws import UNet3p_res_ocr_SNws   # noqa: E402
 from utils.metrics import Evaluator            # noqa: E402
 from utils.loss import SegmentationLosses      # noqa: E402
 from utils.lr_scheduler import LR_Scheduler    # noqa: E402
@@ -48,7 +50,7 @@ torch.set_num_threads(8)
 
 
 sys.path.insert(0, HERE)
-from patterns import (fill, label_pattern, t32, det_init, synth_batch,  # noqa: E402
+from patterns import (fill, label_pattern, t32, det_init, det_init_ocr, synth_batch,  # noqa: E402
                       synth_batch_learnable)
 
 
@@ -162,30 +164,60 @@ def gen_switchnorm():
 
 
 # --------------------------------------------------------------------------- G4
-def gen_models():
+def _run_model(cls, tag, dtype):
     crit = SegmentationLosses(weight=None, cuda=False).build_loss(mode="ce")
-    for cls, tag in ((UNet_SNws, "unet"), (UNet3p_SNws, "unet3p")):
-        model = cls(14, 4, 10, 1, 1)
+    model = cls(14, 4, 10, 1, 1)
+    if tag == "unet3p_res_ocr":
+        det_init_ocr(model)
+        model.ocr_distri_head.conv_bn_dropout[3].p = 0.0
+    else:
         det_init(model)
-        model.train()
-        img, lab = synth_batch(2, 14, 64, 101)
-        out = model(img)
-        loss = crit(out, lab)
-        loss.backward()
-        arrays = {"logits": out.detach().numpy(), "loss": np.array(loss.item(), dtype=np.float64)}
-        names = []
-        for name, p in model.named_parameters():
-            names.append(name)
-            arrays["grad:" + name] = (p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
-        for name, b in model.named_buffers():
-            arrays["buf:" + name] = b.numpy().copy()
-        arrays["param_names"] = np.array(names)
-        arrays["state_keys"] = np.array(list(model.state_dict().keys()))
-        arrays["state_shapes"] = np.array([",".join(map(str, v.shape)) for v in model.state_dict().values()])
-        # eval-mode logits with the running buffers after that one training forward
-        model.eval()
-        with torch.no_grad():
-            arrays["logits_eval"] = model(img).numpy()
+    model = model.to(dtype)
+    model.train()
+    img, lab = synth_batch(2, 14, 64, 101)
+    img = img.to(dtype)
+    out = model(img)
+    loss = crit(out, lab)
+    loss.backward()
+    arrays = {"logits": out.detach().numpy(), "loss": np.array(loss.item(), dtype=np.float64)}
+    names = []
+    for name, p in model.named_parameters():
+        names.append(name)
+        arrays["grad:" + name] = (p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), out.detach().numpy().dtype))
+    for name, b in model.named_buffers():
+        arrays["buf:" + name] = b.numpy().copy()
+    arrays["param_names"] = np.array(names)
+    arrays["state_keys"] = np.array(list(model.state_dict().keys()))
+    arrays["state_shapes"] = np.array([",".join(map(str, v.shape)) for v in model.state_dict().values()])
+    # eval-mode logits with the running buffers after that one training forward
+    model.eval()
+    with torch.no_grad():
+        arrays["logits_eval"] = model(img).numpy()
+    return arrays
+
+
+def gen_models(only=None):
+    for cls, tag in ((UNet_SNws, "unet"), (UNet3p_SNws, "unet3p"), (UNet3p_res_ocr_SNws, "unet3p_res_ocr")):
+        if only and tag not in only:
+            continue
+        if tag != "unet3p_res_ocr":
+            save("g4_" + tag, **_run_model(cls, tag, torch.float32))
+            continue
+        # The res-OCR model at this toy size (batch 2, 4x4 deepest map, BatchNorm over two images) amplifies float32
+        # rounding to ~4e-3 of the logits, so the reference is run in float64 for the expected values and once more
+        # in float32 to record how far the reference's own float32 arithmetic is from them ("gap:*" = max absolute
+        # difference per tensor; some gradients are exactly 0 in exact arithmetic, e.g. a conv bias in front of BN).  Expected tensors are stored as float32 to keep the file small.
+        exact = _run_model(cls, tag, torch.float64)
+        single = _run_model(cls, tag, torch.float32)
+        arrays = {}
+        for k, v in exact.items():
+            if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.ndim > 0:
+                arrays[k] = v.astype(np.float32)
+                if k.startswith(("grad:", "logits")):
+                    arrays["gap:" + k] = np.array(np.abs(single[k].astype(np.float64) - v).max())
+            else:
+                arrays[k] = v
+        arrays["gap:loss"] = np.array(abs(float(single["loss"]) - float(exact["loss"])))
         save("g4_" + tag, **arrays)
 
 
@@ -320,6 +352,8 @@ if __name__ == "__main__":
         gen_switchnorm()
     if "g4" in which:
         gen_models()
+    if "g4ocr" in which:    # only the res-OCR model (the other G4 fixtures stay as committed)
+        gen_models(only=("unet3p_res_ocr",))
     if "g5" in which:
         gen_loss_curve()
     if "g5b" in which:      # MFMA-aligned widths (16..256 channels) for the bf16 tier's 200-step curve

@@ -44,6 +44,21 @@ def det_init(model):
                 p.copy_(t32(fill(tuple(p.shape), k, 0.1)))
 
 
+def det_init_ocr(model):
+    """det_init, then better-conditioned values for what UNet3p_res_ocr_SNws adds to the SNws blocks: BatchNorm2d
+    gammas around 1 and the plain (not standardized) nn.Conv2d filters scaled by 1.5/sqrt(fan_in)."""
+    det_init(model)
+    plain = ("aux_head.", "conv3x3_ocr.", "ocr_distri_head.", "cls_head.", "output_seg_map.")
+    with torch.no_grad():
+        for k, (name, p) in enumerate(model.named_parameters()):
+            if not name.startswith(plain):
+                continue
+            if p.dim() == 4:
+                p.copy_(t32(fill(tuple(p.shape), k, 1.5 / np.sqrt(p.shape[1] * p.shape[2] * p.shape[3]))))
+            elif name.endswith(".weight"):                   # BatchNorm2d gamma (C,)
+                p.copy_(t32(fill(tuple(p.shape), k, 0.25, 1.0)))
+
+
 def synth_batch(B, C, S, k):
     img = fill((B, C, S, S), k, 127.5, 127.5) * (0.6 + 0.4 * np.cos(0.011 * np.arange(S))[None, None, None, :])
     lab = label_pattern((B, S, S), 10, ignore_every=97)

@@ -189,14 +189,37 @@ def test_conv_of_upsampled_commutes(k, ks):
 
 
 # ---------------------------------------------------------------- whole models
-def _state_from_pattern(arch, nf=4):
-    st = O.make_state(arch, 14, nf, 10)
+def _state_from_pattern(arch, nf=4, dtype=torch.float32):
+    st = O.make_state(arch, 14, nf, 10, dtype)
 
     class _M:  # adapter so patterns.det_init can walk "named_parameters" in the reference's order
         def named_parameters(self_inner):
             return [(k, v) for k, v in st.items() if not O.is_buffer(k)]
-    patterns.det_init(_M())
+    (patterns.det_init_ocr if arch == "unet3p_res_ocr" else patterns.det_init)(_M())
     return st
+
+
+def test_res_ocr_model_golden():
+    """UNet3p_res_ocr_SNws: the fixture holds the reference run in float64 (this toy size amplifies float32 rounding
+    to 1e-3..1e-1 of some gradients, recorded in the fixture as "gap:*"), so the oracle is run in float64 too and
+    must agree to the float32 precision the fixture is stored in."""
+    arch, g = "unet3p_res_ocr", load("g4_unet3p_res_ocr")
+    st = _state_from_pattern(arch, dtype=torch.float64)
+    assert list(st.keys()) == [str(k) for k in g["state_keys"]]
+    assert [",".join(map(str, v.shape)) for v in st.values()] == [str(s) for s in g["state_shapes"]]
+    img, lab = patterns.synth_batch(2, 14, 64, 101)
+    logits, loss, grads = O.model_step(arch, st, img.double(), lab, training=True)
+    close(logits, g["logits"], rtol=1e-6, atol=1e-6)
+    assert abs(loss - float(g["loss"])) <= 1e-9 * abs(float(g["loss"]))
+    for name in g["param_names"]:
+        name = str(name)
+        ref = g["grad:" + name]
+        assert np.abs(grads[name].numpy() - ref).max() <= 1e-6 * np.abs(ref).max() + 1e-9, name
+    for k in st:
+        if O.is_buffer(k):
+            close(st[k].double(), g["buf:" + k].astype(np.float64), rtol=1e-6)
+    logits_eval, _, _ = O.model_step(arch, st, img.double(), lab, training=False)
+    close(logits_eval, g["logits_eval"], rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("arch,tag", [("unet", "g4_unet"), ("unet3p", "g4_unet3p")])
@@ -217,7 +240,7 @@ def test_model_golden(arch, tag):
         assert np.abs(got - ref).max() <= 2e-3 * denom + 1e-6, name
     for k in st:
         if O.is_buffer(k):
-            close(st[k], g["buf:" + k], rtol=1e-4)
+            close(st[k].double(), g["buf:" + k].astype(np.float64), rtol=1e-4)
     logits_eval, _, _ = O.model_step(arch, st, img, lab, training=False)
     close(logits_eval, g["logits_eval"], rtol=1e-3, atol=1e-4)
 
