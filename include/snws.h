@@ -196,6 +196,31 @@ int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy, const floa
 int snws_upconv_bwd(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dtype, int N, int h, int w, int C_out,
                     int k, int ksize, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused soft-max cross-entropy, forward + backward in one pass - replaces nn.CrossEntropyLoss(ignore_index=255)
+ * at utils/loss.py:146-159 (called at train.py:252) and its autograd.
+ *
+ * logits (n_pixels, ld) NHWC, C classes, dtype SNWS_F32 | SNWS_BF16; target f32 labels (truncated toward zero like
+ * .long()); pixels whose label equals ignore_index contribute nothing.
+ * loss_part[snws_ce_blocks(n_pixels)]: per-block sums of (logsumexp - logit[target]) in a fixed order; the caller
+ *   adds them and divides by (valid pixels * batch size) - both global under data parallelism.
+ * dlogits (n_pixels, ldd), may be NULL: (softmax - onehot) * *scale for valid pixels, 0 otherwise; channels
+ *   C..c_write-1 (the MFMA head's padding) are written as 0.  scale: device scalar 1/(valid * batch), or NULL = 1. */
+int snws_ce_blocks(int64_t n_pixels);
+int snws_ce_fwd_bwd(const void* logits, int dtype, int64_t ld, const float* target, int64_t n_pixels, int C,
+                    int ignore_index, const float* scale, float* loss_part, void* dlogits, int64_t ldd, int c_write,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Arg-max of one inference tile written into the full-disk prediction - replaces torch.max(outputs, 1) and
+ * pred_arr[yoff:yoff+B, xoff:xoff+B] = tile at predict.py:196,248-253 (tiles are stitched in list order, a later
+ * tile overwrites an earlier one where they overlap).
+ * logits (h*w, ld) NHWC of one tile; pred int64 (H, W); the tile's top-left pixel lands at (y0, x0); pixels that
+ * fall outside the disk are dropped.  First maximum wins, a NaN counts as the maximum (torch.max / numpy.argmax).
+ * remap_background != 0 applies predict.py:207-213 (classes 0 and 10 -> 255). */
+int snws_argmax_stitch(const void* logits, int dtype, int64_t ld, int h, int w, int C, int64_t* pred, int H, int W,
+                       int y0, int x0, int remap_background, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ class UNet3p_SNws(nn.Module):
         self.conv_fusion = ConvSnRelu(5 * f, 5 * f, **kw)
         self.output_seg_map = nn.Conv2d(5 * f, n_class, kernel_size=1, stride=1, padding=0)
         self.compute_dtype = None      # None: keep the input's dtype; torch.bfloat16 for the MFMA tier
+        self.raw_logits = False        # True: return the head kernel's own (padded, compute-dtype) output
 
     def forward(self, x):
         x = to_device_layout(x, self.compute_dtype)
@@ -41,4 +42,4 @@ class UNet3p_SNws(nn.Module):
                 t = ops.max_pool_ceil(t, 2)
             t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
             enc[lvl] = t
-        return head_conv(self.output_seg_map, full_scale_decoder(self, enc))
+        return head_conv(self.output_seg_map, full_scale_decoder(self, enc), raw=self.raw_logits)

@@ -161,6 +161,7 @@ class UNet3p_res_ocr_SNws(nn.Module):
         self.conv_fusion = ConvSnRelu(5 * f, 5 * f, **kw)
         self.output_seg_map = nn.Conv2d(f, n_class, kernel_size=1, stride=1, padding=0)   # registered, unused (:294)
         self.compute_dtype = None      # None: keep the input's dtype; torch.bfloat16 for the MFMA tier
+        self.raw_logits = False        # True: return the head kernel's own (padded, compute-dtype) output
 
     def forward(self, x):
         x = to_device_layout(x, self.compute_dtype)
@@ -176,4 +177,4 @@ class UNet3p_res_ocr_SNws(nn.Module):
         feats = self.conv3x3_ocr(convu1)
         context = self.ocr_gather_head(feats, out_aux)
         feats = self.ocr_distri_head(feats, context)
-        return head_conv(self.cls_head, feats)
+        return head_conv(self.cls_head, feats, raw=self.raw_logits)

@@ -27,6 +27,7 @@ class UNet_SNws(nn.Module):
         self.conv7_1, self.conv7_2, self.conv7_3 = block(2 * f, f, 1), block(2 * f, f), block(f, f)
         self.output_seg_map = nn.Conv2d(f, n_class, kernel_size=(1, 1), stride=1, padding=0)
         self.compute_dtype = None
+        self.raw_logits = False        # True: return the head kernel's own (padded, compute-dtype) output
 
     def forward(self, x):
         x = to_device_layout(x, self.compute_dtype)
@@ -41,4 +42,4 @@ class UNet_SNws(nn.Module):
                               (self.conv6_1, self.conv6_2, self.conv6_3), (self.conv7_1, self.conv7_2, self.conv7_3)):
             x = up1.on_upsampled(x, 2)       # 1x1 conv of the x2 up-sampled map, computed at low resolution
             x = c3(c2(crop_concat(skips.pop(), x)))
-        return head_conv(self.output_seg_map, x)
+        return head_conv(self.output_seg_map, x, raw=self.raw_logits)

@@ -74,7 +74,7 @@ def to_device_layout(x, dtype=None):
     return x.contiguous(memory_format=torch.channels_last)
 
 
-def plain_conv(conv, x):
+def plain_conv(conv, x, raw=False):
     """A plain (not standardized) stride-1 'same' nn.Conv2d through the library's own conv kernels, in x's dtype.
     For bf16 activations the filter is zero-padded to a multiple of 16 output channels so the MFMA kernels take
     it; the padding is sliced off again (autograd sees plain pad/slice ops)."""
@@ -89,11 +89,14 @@ def plain_conv(conv, x):
         w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, pad))
         b = None if b is None else torch.nn.functional.pad(b, (0, pad))
     y = ops.PlainConvFn.apply(x, w, b)
-    return y[:, :n_out] if pad else y
+    return y if (raw or not pad) else y[:, :n_out]
 
 
-def head_conv(conv, x):
-    """The plain nn.Conv2d 1x1 classification head (modeling/UNet3p_SNws.py:93,158); returns float32 logits."""
+def head_conv(conv, x, raw=False):
+    """The plain nn.Conv2d 1x1 classification head (modeling/UNet3p_SNws.py:93,158); returns float32 logits, or
+    with raw=True the kernel's own output (compute dtype, channels padded to 16 for bf16) for the fused loss."""
+    if raw:
+        return plain_conv(conv, x, raw=True)
     return plain_conv(conv, x).float()
 
 

@@ -58,11 +58,14 @@ _SIGNATURES = {
     "snws_resample_fwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_resample_bwd": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   P]),
+    "snws_ce_blocks": (c_int, [c_int64]),
+    "snws_ce_fwd_bwd": (c_int, [P, c_int, c_int64, P, c_int64, c_int, c_int, P, P, P, c_int64, c_int, P]),
+    "snws_argmax_stitch": (c_int, [P, c_int, c_int64, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
 }
 
 # entry points that return a status code (the others return a value)
 _STATUS = {k for k, (res, _) in _SIGNATURES.items() if res is c_int} - {
-    "snws_version", "snws_conv_out_size", "snws_conv_mfma_tiles", "snws_sn_stats_tiles"}
+    "snws_version", "snws_conv_out_size", "snws_conv_mfma_tiles", "snws_sn_stats_tiles", "snws_ce_blocks"}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -65,6 +65,24 @@ def global_ce_loss(logits, target, ignore_index=255, group=None):
     return ce_sum / cnt[0] / cnt[1]
 
 
+def global_ce_loss_fused(raw_logits, n_class, target, ignore_index=255, group=None):
+    """global_ce_loss on the head kernel's raw output (N, Cp, H, W) through the fused forward+backward kernel: the
+    soft-max, the loss and d(loss)/d(logits) are produced in one pass over the logits."""
+    from . import ops
+    n = raw_logits.shape[0]
+    cnt = torch.stack([(target.to(torch.int64) != ignore_index).sum().to(torch.float32),
+                       torch.tensor(float(n), device=raw_logits.device)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if cnt.is_cuda and dist.get_backend(group) == "gloo":
+            h = cnt.cpu()
+            dist.all_reduce(h, group=group)
+            cnt = h.to(cnt.device)
+        else:
+            dist.all_reduce(cnt, group=group)
+    scale = 1.0 / (cnt[0] * cnt[1])
+    return ops.FusedCEFn.apply(raw_logits, target, n_class, scale, ignore_index)
+
+
 class GradBuckets:
     """Sum-all-reduce of parameter gradients in ~bucket_mb buckets, overlapped with backward.
 
@@ -146,8 +164,12 @@ class Trainer:
     """One-replica training driver with the reference's hyper-parameters as defaults (train.py:384-429)."""
 
     def __init__(self, model, lr=0.002, weight_decay=5e-4, total_iters=1000, ignore_index=255, group=None,
-                 bucket_mb=25.0):
+                 bucket_mb=25.0, fused_loss=None):
         self.model = model
+        # classes = output channels of the last registered 1x1 classification conv the forward uses
+        head = getattr(model, "cls_head", None) or getattr(model, "output_seg_map")
+        self.n_class = head.out_channels
+        self.fused_loss = hasattr(model, "raw_logits") if fused_loss is None else bool(fused_loss)
         self.base_lr, self.total_iters, self.ignore_index, self.group = lr, total_iters, ignore_index, group
         try:
             self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, fused=True)
@@ -166,8 +188,16 @@ class Trainer:
             g["lr"] = lr
         self.opt.zero_grad(set_to_none=True)
         self.model.train()
-        out = self.model(image)
-        loss = global_ce_loss(out, target, self.ignore_index, self.group)
+        if self.fused_loss:
+            self.model.raw_logits = True
+            try:
+                out = self.model(image)
+            finally:
+                self.model.raw_logits = False
+            loss = global_ce_loss_fused(out, self.n_class, target, self.ignore_index, self.group)
+        else:
+            out = self.model(image)
+            loss = global_ce_loss(out, target, self.ignore_index, self.group)
         loss.backward()
         self.buckets.finish()
         self.opt.step()

@@ -625,6 +625,52 @@ class AssembleFn(torch.autograd.Function):
         return tuple(outs)
 
 
+# ------------------------------------------------------------------------------------------------ loss / inference tiles
+class FusedCEFn(torch.autograd.Function):
+    """scale * sum over non-ignored pixels of CrossEntropy(logits, target) (utils/loss.py:146-159 with the division
+    by the valid-pixel count and the batch size folded into `scale`, a device scalar), forward and backward in one
+    pass.  logits: (N, Cp, H, W) channels-last, the first n_class channels are real (Cp > n_class: the padded MFMA
+    head); the gradient of the padding channels is zero."""
+
+    @staticmethod
+    def forward(ctx, logits, target, n_class, scale, ignore_index):
+        require_gpu(logits, "cross entropy")
+        N, Cp, H, W = logits.shape
+        xs, ld = as_nhwc(logits)
+        tg = target.detach().to(torch.float32).contiguous()
+        if tuple(tg.shape) != (N, H, W):
+            raise ValueError("cross entropy: target shape %s does not match logits %s" % (tuple(tg.shape), (N, H, W)))
+        npix = N * H * W
+        part = torch.empty(L.lib().snws_ce_blocks(npix), dtype=torch.float32, device=logits.device)
+        dl = new_nhwc(N, Cp, H, W, xs.dtype, logits.device)
+        sc = scale.detach().to(torch.float32).reshape(1).contiguous()
+        _launch("ce_fwd_bwd", float(npix) * (2.0 * xs.element_size() * Cp + 4.0), "snws_ce_fwd_bwd", _ptr(xs),
+                dtype_code(xs), ld, _ptr(tg), npix, int(n_class), int(ignore_index), _ptr(sc), _ptr(part), _ptr(dl), Cp,
+                Cp, _stream())
+        ctx.dl = dl
+        return part.sum() * sc[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, ctx.dl = ctx.dl, None
+        return dl.mul_(g.to(dl.dtype)), None, None, None, None
+
+
+def argmax_stitch(logits, n_class, pred, y0, x0, remap_background=False):
+    """pred[y0:y0+h, x0:x0+w] = argmax over the first n_class channels of ONE tile's logits (1, Cp, h, w), clipped
+    to pred's extent (predict.py:196,248-253).  pred: int64 (H, W) on the device."""
+    require_gpu(logits, "argmax_stitch")
+    if logits.dim() != 4 or logits.shape[0] != 1:
+        raise ValueError("argmax_stitch takes one tile (1, C, h, w)")
+    if pred.dtype != torch.int64 or pred.dim() != 2 or not pred.is_contiguous():
+        raise ValueError("argmax_stitch: pred must be a contiguous int64 (H, W) tensor")
+    xs, ld = as_nhwc(logits)
+    _, _, h, w = logits.shape
+    L.call("snws_argmax_stitch", _ptr(xs), dtype_code(xs), ld, h, w, int(n_class), _ptr(pred), pred.shape[0],
+           pred.shape[1], int(y0), int(x0), int(bool(remap_background)), _stream())
+    return pred
+
+
 # ------------------------------------------------------------------------------------------------ resampling
 _MODE = {"copy": 0, "maxpool": 1, "bilinear": 2}
 

@@ -117,3 +117,15 @@ def test_poly_lr_and_tiles(golden_dir):
     g = np.load(os.path.join(golden_dir, "g78_misc.npz"))
     for (i, ep), lr in zip(g["lr_pts"], g["lr_vals"]):
         assert harness.poly_lr(0.002, int(ep) * 746 + int(i), 200 * 746) == lr
+
+
+def test_tile_offsets_match_golden():
+    """snws.tiles.gen_tiles_offs (host side of the full-disk inference path) against the vectors produced by the
+    reference's utils/gen_tiles_offs.py:3-27."""
+    import numpy as np
+    from snws import tiles
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g78_misc.npz"))
+    for i in range(int(g["n_tiles_cases"])):
+        args = [int(v) for v in g["tiles%d_args" % i]]
+        assert np.array_equal(np.array(tiles.gen_tiles_offs(*args), np.int64), g["tiles%d" % i])
+    assert len(tiles.gen_tiles_offs(2748, 2748, 512, 0)) == 36

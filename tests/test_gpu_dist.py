@@ -72,6 +72,25 @@ def _worker(rank, world, port, q):
     full_pred = np.argmax(g["logits"], axis=1)
     errs["cm_equal"] = bool(np.array_equal(ev.confusion_matrix,
                                            O.confusion_matrix(lab.numpy(), full_pred, 10).astype(np.float64)))
+    # fused loss head under data parallelism: same global normalisation as the unfused loss
+    model.zero_grad(set_to_none=True)
+    model.raw_logits = True
+    raw = model(img[rank:rank + 1].to(dev))
+    model.raw_logits = False
+    lf = harness.global_ce_loss_fused(raw, 10, lab[rank:rank + 1].to(dev))
+    errs["fused_loss"] = abs(float(lf) - float(loss)) / abs(float(loss))
+    # full-disk inference sharded over the ranks == the same call on one rank alone (tiles overlap: later tile wins)
+    from snws import tiles
+    big, _ = patterns.synth_batch(1, 14, 160, 7)
+    disk = big[0, :, :150, :].to(dev)
+    got = tiles.predict_disk(model, disk, block=64, overlap=24, tiles_per_forward=2)
+    offs = tiles.gen_tiles_offs(160, 150, 64, 24)
+    ref = torch.zeros((150, 160), dtype=torch.int64, device=dev)
+    model.eval()
+    with torch.no_grad():
+        for (x, y) in offs:
+            ref[y:y + 64, x:x + 64] = torch.argmax(model(disk[None, :, y:y + 64, x:x + 64])[0], dim=0)
+    errs["disk_equal"] = bool(torch.equal(got, ref))
     q.put((rank, errs, len(buckets.buckets)))
     dist.destroy_process_group()
 
@@ -91,4 +110,4 @@ def test_two_rank_step_equals_reference_full_batch():
         print(rank, errs, nb)
         assert nb >= 2
         assert errs["logits"] < 1e-3 and errs["loss"] < 1e-3 and errs["grads"] < 3e-3 and errs["buffers"] < 1e-3
-        assert errs["cm_equal"]
+        assert errs["cm_equal"] and errs["disk_equal"] and errs["fused_loss"] < 1e-5

@@ -728,3 +728,102 @@ def test_loss_curve_bf16_tracks_reference():
     assert sm.max() < 0.30
     assert abs(got[-10:].mean() - ref[-10:].mean()) < 0.15 * ref[-10:].mean()
     assert got[-1] < 0.5 * got[0]
+
+
+# ---------------------------------------------------------------- fused loss, tiled inference
+@pytest.mark.parametrize("dtype,cp", [(torch.float32, 10), (torch.bfloat16, 16), (torch.bfloat16, 10), (torch.float32, 3)])
+def test_fused_cross_entropy_vs_torch(dtype, cp):
+    """FusedCEFn == CrossEntropyLoss(ignore_index=255, reduction='sum') * scale and its gradient (utils/loss.py:
+    146-159), with float labels, ignored pixels and the padded head (channels n_class..cp-1 get zero gradient)."""
+    from snws import ops
+    torch.manual_seed(4)
+    n_class = min(cp, 10)
+    N, H, W = 3, 37, 29
+    logits = (torch.randn(N, cp, H, W) * 3).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    target = torch.randint(0, n_class, (N, H, W)).float()
+    target[0, :5] = 255.0
+    target[2, 7, 3] = 255.0
+    target = target.to(DEV)
+    scale = torch.tensor(1.0 / (float((target != 255).sum()) * N), device=DEV)
+    loss = ops.FusedCEFn.apply(logits, target, n_class, scale, 255)
+    (loss * 1.5).backward()
+    ref_in = logits.detach()[:, :n_class].float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, target.long(), ignore_index=255, reduction="sum") * scale
+    (ref * 1.5).backward()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert relerr(logits.grad[:, :n_class].float(), ref_in.grad) < tol
+    if cp > n_class:
+        assert float(logits.grad[:, n_class:].abs().max()) == 0.0
+    # the reference's own composition: mean over valid pixels, then / batch
+    ref2 = torch.nn.functional.cross_entropy(ref_in.detach(), target.long(), ignore_index=255) / N
+    assert abs(float(loss) - float(ref2)) <= 1e-5 * abs(float(ref2))
+
+
+def test_trainer_fused_loss_matches_unfused():
+    """One Trainer.step with the fused loss head gives the same loss and the same parameter gradients as the
+    float32-logits + torch cross-entropy path."""
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from snws import harness
+    img, lab = patterns.synth_batch(2, 14, 64, 101)
+    grads, losses = [], []
+    for fused in (False, True):
+        model = UNet3p_SNws(14, 4, 10, 1, 1)
+        patterns.det_init(model)
+        model = model.to(DEV)
+        tr = harness.Trainer(model, fused_loss=fused)
+        tr.opt.step = lambda *a, **k: None        # keep the gradients of this one step
+        losses.append(float(tr.step(img.to(DEV), lab.to(DEV))))
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters()})
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[0])
+    for n in grads[0]:
+        assert relerr(grads[1][n], grads[0][n]) < 1e-4 or float(grads[0][n].abs().max()) < 1e-7, n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_argmax_stitch_vs_torch(dtype):
+    from snws import ops
+    torch.manual_seed(6)
+    H, W, b = 70, 90, 32
+    pred = torch.full((H, W), -1, dtype=torch.int64, device=DEV)
+    ref = pred.clone()
+    for (y, x) in [(0, 0), (20, 50), (38, 58), (60, 80)]:          # overlapping, and one tile hanging over the border
+        lg = torch.randn(1, 16, b, b).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+        lg[0, 3, 5, 7] = float("nan")
+        lg[0, :, 9, 9] = 1.0                                         # tie: first maximum
+        ops.argmax_stitch(lg, 10, pred, y, x)
+        am = torch.argmax(lg[0, :10].float(), dim=0)
+        hh, ww = min(b, H - y), min(b, W - x)
+        ref[y:y + hh, x:x + ww] = am[:hh, :ww]
+    assert torch.equal(pred, ref)
+    lg = torch.zeros(1, 11, 4, 4, device=DEV).contiguous(memory_format=torch.channels_last)
+    lg[0, 10, 0, 0] = 1.0
+    lg[0, 4, 1, 1] = 1.0
+    out = torch.zeros((4, 4), dtype=torch.int64, device=DEV)
+    ops.argmax_stitch(lg, 11, out, 0, 0, remap_background=True)
+    assert int(out[0, 0]) == 255 and int(out[1, 1]) == 4 and int(out[2, 2]) == 255     # classes 10 and 0 -> 255
+
+
+def test_predict_disk_matches_tile_by_tile():
+    """predict_disk (batched tiles, on-device arg-max + stitch) == the reference's loop written with plain torch:
+    tile offsets from the oracle's gen_tiles_offs, one eval forward per tile, argmax, later tile overwrites."""
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from snws import tiles
+    model = UNet3p_SNws(14, 4, 10, 1, 1)
+    patterns.det_init(model)
+    model = model.to(DEV)
+    img, _ = patterns.synth_batch(1, 14, 160, 7)
+    disk = img[0, :, :150, :].to(DEV)                                # (14, 150, 160): H = 150, W = 160
+    for block, overlap in ((64, 0), (64, 24)):
+        offs = O.gen_tiles_offs(160, 150, block, overlap)
+        assert tiles.gen_tiles_offs(160, 150, block, overlap) == offs
+        ref = torch.zeros((150, 160), dtype=torch.int64, device=DEV)
+        model.eval()
+        with torch.no_grad():
+            for (x, y) in offs:
+                lg = model(disk[None, :, y:y + block, x:x + block])
+                ref[y:y + block, x:x + block] = torch.argmax(lg[0], dim=0)
+        got = tiles.predict_disk(model, disk, block=block, overlap=overlap, tiles_per_forward=3)
+        assert got.shape == ref.shape
+        # eval-mode SwitchNorm has no batch coupling, so batching tiles changes nothing: exact equality
+        assert torch.equal(got, ref)
