@@ -221,6 +221,20 @@ int snws_ce_fwd_bwd(const void* logits, int dtype, int64_t ld, const float* targ
 int snws_argmax_stitch(const void* logits, int dtype, int64_t ld, int h, int w, int C, int64_t* pred, int H, int W,
                        int y0, int x0, int remap_background, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Collectives for hosts without their own - the exchange points of the data-parallel path as in-place all-reduces
+ * over RCCL, loaded at run time.  Replaces the SyncMaster / SlavePipe rendez-vous of
+ * modeling/sync_batchnorm/comm.py:39-43,71-90 (SwitchNorm / BN statistics: the `pack` buffers of snws_sn_mix_a and
+ * snws_sn_bwd_mix_a), DataParallel's gradient reduction (train.py:85,253) and the per-replica confusion matrices
+ * (train.py:301).  One communicator per process, created on the current HIP device.
+ * snws_comm_unique_id: rank 0 fills 128 bytes, the host hands them to every rank (file, socket, MPI ...). */
+typedef struct snws_comm snws_comm;
+int snws_comm_unique_id(void* id128);
+int snws_comm_init(const void* id128, int rank, int world, snws_comm** out);
+int snws_comm_allreduce_f32(snws_comm* comm, float* buf, int64_t count, void* stream);              /* sum */
+int snws_comm_allreduce_i64(snws_comm* comm, int64_t* buf, int64_t count, int op, void* stream);    /* op 0 sum, 1 max */
+int snws_comm_destroy(snws_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

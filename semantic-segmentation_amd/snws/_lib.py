@@ -58,6 +58,11 @@ _SIGNATURES = {
     "snws_resample_fwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_resample_bwd": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   P]),
+    "snws_comm_unique_id": (c_int, [P]),
+    "snws_comm_init": (c_int, [P, c_int, c_int, P]),
+    "snws_comm_allreduce_f32": (c_int, [P, P, c_int64, P]),
+    "snws_comm_allreduce_i64": (c_int, [P, P, c_int64, c_int, P]),
+    "snws_comm_destroy": (c_int, [P]),
     "snws_ce_blocks": (c_int, [c_int64]),
     "snws_ce_fwd_bwd": (c_int, [P, c_int, c_int64, P, c_int64, c_int, c_int, P, P, P, c_int64, c_int, P]),
     "snws_argmax_stitch": (c_int, [P, c_int, c_int64, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -827,3 +827,21 @@ def test_predict_disk_matches_tile_by_tile():
         assert got.shape == ref.shape
         # eval-mode SwitchNorm has no batch coupling, so batching tiles changes nothing: exact equality
         assert torch.equal(got, ref)
+
+
+def test_comm_single_rank_roundtrip():
+    """The C ABI's own RCCL collectives on a one-rank communicator: all-reduce(sum / max) leaves the buffers as they
+    are.  (More ranks need more GPUs than the test box has; the multi-rank path is the same call.)"""
+    from snws.comm import Comm
+    c = Comm(Comm.unique_id(), 0, 1)
+    a = torch.arange(1000, dtype=torch.float32, device=DEV) * 0.5
+    b = torch.arange(100, dtype=torch.int64, device=DEV) - 50
+    a0, b0 = a.clone(), b.clone()
+    c.all_reduce(a)
+    c.all_reduce(b, "sum")
+    c.all_reduce(b, "max")
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    with pytest.raises(TypeError):
+        c.all_reduce(a, "max")
+    c.close()
