@@ -1,6 +1,7 @@
 """GPU parity tests: every HIP kernel, called through the C ABI (via the host modules), against the CPU oracle and
 the reference-generated golden fixtures.  Run on the MI355X box with `-m gpu`."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ import patterns
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
@@ -429,7 +431,9 @@ def test_fused_conv_sn_relu_block_bf16_vs_oracle(shape):
     (2, 6, 4, 5, 7, 2, 3, torch.float32, 1e-4), (1, 5, 3, 3, 2, 8, 3, torch.float32, 1e-4),
     (2, 8, 8, 4, 4, 16, 3, torch.float32, 1e-4), (2, 16, 8, 6, 5, 2, 1, torch.float32, 1e-4),
     (2, 64, 64, 8, 8, 4, 3, torch.bfloat16, 2e-2), (1, 320, 64, 8, 16, 2, 3, torch.bfloat16, 2e-2),
-    (1, 128, 64, 2, 2, 16, 3, torch.bfloat16, 2e-2), (2, 64, 32, 8, 8, 2, 1, torch.bfloat16, 2e-2)])
+    (1, 128, 64, 2, 2, 16, 3, torch.bfloat16, 2e-2), (2, 64, 32, 8, 8, 2, 1, torch.bfloat16, 2e-2),
+    (2, 16, 16, 5, 3, 8, 3, torch.float32, 1e-4), (1, 64, 72, 3, 5, 8, 3, torch.bfloat16, 2e-2),
+    (1, 32, 64, 3, 3, 16, 3, torch.bfloat16, 2e-2)])
 def test_conv_of_upsampled_map_vs_oracle(case):
     """ConvSnRelu.on_upsampled(x, k) - the 1x1 'tap' conv at low resolution followed by the gather kernel - equals
     ConvSnRelu(nn.Upsample(k, bilinear)(x)) of the oracle, forward and every gradient."""
@@ -845,3 +849,40 @@ def test_comm_single_rank_roundtrip():
     with pytest.raises(TypeError):
         c.all_reduce(a, "max")
     c.close()
+
+
+def test_upconv_separable_kernel_all_factors():
+    """The separable up-sampled-conv forward kernel is the default for k >= 8 only; with SNWS_UPCONV_SEP_ALL=1 (read
+    once per process, hence the child process) it also takes k = 2 and 4.  Its output must equal the per-pixel
+    gather kernel's (float32: 1e-6) for every factor, including heights/widths that are not multiples of its 8x32
+    strip."""
+    import subprocess
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join(%r, "semantic-segmentation_amd"))
+from snws import _lib as L
+out = {}
+torch.manual_seed(0)
+for k, h, w in ((2, 3, 5), (2, 9, 20), (4, 3, 2), (4, 5, 9), (8, 2, 5), (16, 1, 3)):
+    Co = 16
+    Z = torch.randn(2, h, w, 9 * Co, device="cuda")
+    b = torch.randn(Co, device="cuda")
+    y = torch.empty(2, h * k, w * k, Co, device="cuda")
+    L.call("snws_upconv_fwd", Z.data_ptr(), 9 * Co, y.data_ptr(), Co, b.data_ptr(), 0, 2, h, w, Co, k, 3, 0)
+    torch.cuda.synchronize()
+    out["k%%d_%%d_%%d" %% (k, h, w)] = y.cpu().numpy()
+np.savez(sys.argv[1], **out)
+""" % ROOT
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, env_extra in enumerate(({"SNWS_UPCONV_GATHER": "1"}, {"SNWS_UPCONV_SEP_ALL": "1"})):
+            env = dict(os.environ)
+            env.update(env_extra)
+            path = os.path.join(d, "o%d.npz" % i)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=200)
+            res.append(dict(np.load(path)))
+    assert set(res[0]) == set(res[1]) and len(res[0]) == 6
+    for key in res[0]:
+        a, b = res[0][key], res[1][key]
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max(), key
