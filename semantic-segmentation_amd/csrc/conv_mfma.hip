@@ -629,35 +629,75 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
     }
   }
 
+  // per-lane staging constants: lane = (pixel q of a piece's 8, 16-byte channel chunk c); the chunk swizzle bit
+  // (pix >> 1) & 1 of pixel 8*i + q only depends on q
+  const int st_q = lane >> 3, st_chunk = (lane & 7) ^ (((st_q >> 1) & 1) << 2);
+  const bool st_dy_ok = cot * 64 + st_chunk * 8 < a.Cout, st_x_ok = cit * 64 + st_chunk * 8 < a.Cin;
+  const unsigned st_dy_off = (unsigned)(((wave * 8 + st_q) * a.lddy + st_chunk * 8) * 2);
+  const int st_px0 = wave * 8 + st_q;                                  // halo pixel 8*wave + q lies in halo row 0
+  const unsigned st_x_off = (unsigned)((st_px0 * a.ldx + st_chunk * 8) * 2);
   for (int t = t_begin; t < t_end; ++t) {
     int tt = t;
     const int tx = tt % a.tilesX; tt /= a.tilesX;
     const int ty = tt % a.tilesY;
     const int n = tt / a.tilesY;
     const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+    if (y0 >= 1 && y0 + WG_TH < a.H && x0 >= 1 && x0 + WG_TW < a.W) {
+      // interior tile (the common case): no per-pixel bounds tests; addresses = tile base + a per-lane offset that
+      // advances by a two-way recurrence from piece to piece (a piece is 8 consecutive halo pixels x 64 channels)
+      const unsigned char* dyb = reinterpret_cast<const unsigned char*>(a.dy + (((int64_t)n * a.H + y0) * a.W + x0) * a.lddy + cot * 64);
+      const int64_t dyrow = (int64_t)a.W * a.lddy * 2;
 #pragma unroll
-    for (int j = 0; j < G::JD; ++j) {
-      const int i = wave + 4 * j;
-      const int pix = i * 8 + (lane >> 3);
-      const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-      const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
-      const bool ok = gy < a.H && gx < a.W && cot * 64 + chunk * 8 < a.Cout;
-      const void* s = ok ? (const void*)(a.dy + (((int64_t)n * a.H + gy) * a.W + gx) * a.lddy + cot * 64 + chunk * 8)
-                         : (const void*)snws_zero_page;
-      glds16(s, dy_lds + i * 1024);
-    }
+      for (int j = 0; j < G::JD; ++j) {       // piece wave + 4j = tile row j, columns 8*wave..8*wave+7
+        const void* s_ = st_dy_ok ? (const void*)(dyb + j * dyrow + st_dy_off) : (const void*)snws_zero_page;
+        glds16(s_, dy_lds + (wave + 4 * j) * 1024);
+      }
+      const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x + (((int64_t)n * a.H + y0 - 1) * a.W + x0 - 1) * a.ldx + cit * 64);
+      const unsigned rowb = (unsigned)a.W * (unsigned)a.ldx * 2u, pixb = (unsigned)a.ldx * 2u;
+      int px_ = st_px0;
+      unsigned xo = st_x_off;
 #pragma unroll
-    for (int j = 0; j < G::JX; ++j) {
-      const int i = wave + 4 * j;
-      if (i < G::XNI) {
-        const int pix = i * 8 + (lane >> 3);
-        const int py = pix / G::HWd, px = pix - py * G::HWd;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
-        const bool ok = pix < G::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cit * 64 + chunk * 8 < a.Cin;
-        const void* s = ok ? (const void*)(a.x + (((int64_t)n * a.H + gy) * a.W + gx) * a.ldx + cit * 64 + chunk * 8)
+      for (int j = 0; j < G::JX; ++j) {
+        const int i = wave + 4 * j;
+        if (i < G::XNI) {
+          const bool ok = st_x_ok && (j < G::JX - 1 || i * 8 + (lane >> 3) < G::NPIX);
+          const void* s_ = ok ? (const void*)(xb + xo) : (const void*)snws_zero_page;
+          glds16(s_, x_lds + i * 1024);
+          // next piece of this wave: 32 halo pixels further in the 34-wide halo rows
+          const bool wrap = px_ >= 2;
+          xo += wrap ? rowb - 2u * pixb : 32u * pixb;
+          px_ += wrap ? -2 : 32;
+        }
+      }
+    } else {
+      // border tile: per-pixel bounds tests, recomputed from an opaque copy of the lane id so that their per-lane
+      // invariants are not hoisted into registers the accumulator-heavy main loop needs
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+  #pragma unroll
+      for (int j = 0; j < G::JD; ++j) {
+        const int i = wave + 4 * j;
+        const int pix = i * 8 + (ln >> 3);
+        const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+        const int chunk = (ln & 7) ^ (((pix >> 1) & 1) << 2);
+        const bool ok = gy < a.H && gx < a.W && cot * 64 + chunk * 8 < a.Cout;
+        const void* s = ok ? (const void*)(a.dy + (((int64_t)n * a.H + gy) * a.W + gx) * a.lddy + cot * 64 + chunk * 8)
                            : (const void*)snws_zero_page;
-        glds16(s, x_lds + i * 1024);
+        glds16(s, dy_lds + i * 1024);
+      }
+  #pragma unroll
+      for (int j = 0; j < G::JX; ++j) {
+        const int i = wave + 4 * j;
+        if (i < G::XNI) {
+          const int pix = i * 8 + (ln >> 3);
+          const int py = pix / G::HWd, px = pix - py * G::HWd;
+          const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+          const int chunk = (ln & 7) ^ (((pix >> 1) & 1) << 2);
+          const bool ok = pix < G::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cit * 64 + chunk * 8 < a.Cin;
+          const void* s = ok ? (const void*)(a.x + (((int64_t)n * a.H + gy) * a.W + gx) * a.ldx + cit * 64 + chunk * 8)
+                             : (const void*)snws_zero_page;
+          glds16(s, x_lds + i * 1024);
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
