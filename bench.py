@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--disk", action="store_true", help="also time full-disk tiled inference (36 tiles of 512^2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--all-kernel-events", action="store_true",
+                    help="bracket EVERY kernel launch with HIP events (fills the `kernels` table; costs ~5 ms of host "
+                         "time per step); default: only the roofline kernel's launches")
     args = ap.parse_args()
 
     from snws import harness, ops
@@ -156,6 +159,7 @@ def main():
         loss = trainer.step(img, lab)
     barrier()
     ops.PROFILE = None if args.no_kernel_events else []
+    ops.PROFILE_ONLY = None if args.all_kernel_events else ("conv_mfma_fwd_k3_kc32", "conv_mfma_dgrad_k3_kc32")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(img, lab)

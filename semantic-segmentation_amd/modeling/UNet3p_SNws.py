@@ -7,7 +7,7 @@ The seven decoder blocks are shared by the four decoder scales, as in the refere
 import torch
 import torch.nn as nn
 
-from modeling.blocks import ConvSnRelu, full_scale_decoder, head_conv, to_device_layout
+from modeling.blocks import ConvSnRelu, PoolPyramid, full_scale_decoder, head_conv, to_device_layout
 from snws import ops
 
 
@@ -36,10 +36,11 @@ class UNet3p_SNws(nn.Module):
     def forward(self, x):
         x = to_device_layout(x, self.compute_dtype)
         enc = {}
+        pools = PoolPyramid(enc)
         t = x
         for lvl, name in enumerate(['convd1', 'convd2', 'convd3', 'convd4', 'conv5'], start=1):
             if lvl > 1:
-                t = ops.max_pool_ceil(t, 2)
+                t = pools.get(lvl - 1, 2)       # shared with the decoder's factor-2 skip of the same map
             t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
             enc[lvl] = t
-        return head_conv(self.output_seg_map, full_scale_decoder(self, enc), raw=self.raw_logits)
+        return head_conv(self.output_seg_map, full_scale_decoder(self, enc, pools), raw=self.raw_logits)

@@ -16,7 +16,7 @@ from torch.nn.modules.utils import _pair
 
 import modeling.snorm as sn
 import modeling.weightstd as ws
-from modeling.blocks import (ConvSnRelu, PlainConv2d, Resnet_BasicBlock, crop_concat as CropConcat,  # noqa: F401
+from modeling.blocks import (ConvSnRelu, PlainConv2d, PoolPyramid, Resnet_BasicBlock, crop_concat as CropConcat,  # noqa: F401
                              full_scale_decoder, head_conv, plain_conv, to_device_layout)
 from snws import ops
 
@@ -166,13 +166,14 @@ class UNet3p_res_ocr_SNws(nn.Module):
     def forward(self, x):
         x = to_device_layout(x, self.compute_dtype)
         enc = {}
+        pools = PoolPyramid(enc)
         t = x
         for lvl, name in enumerate(['convd1', 'convd2', 'convd3', 'convd4', 'conv5'], start=1):
             if lvl > 1:
-                t = ops.max_pool_ceil(t, 2)
+                t = pools.get(lvl - 1, 2)       # shared with the decoder's factor-2 skip of the same map
             t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
             enc[lvl] = t
-        convu1 = full_scale_decoder(self, enc)
+        convu1 = full_scale_decoder(self, enc, pools)
         out_aux = self.aux_head(convu1)
         feats = self.conv3x3_ocr(convu1)
         context = self.ocr_gather_head(feats, out_aux)

@@ -136,12 +136,36 @@ class Resnet_BasicBlock(nn.Module):
                                          c2.prepared(mf and not c2.force_direct), ops.SNParams(n2), x)
 
 
-def full_scale_decoder(m, enc):
+class PoolPyramid:
+    """Max-pooled copies of the encoder maps, each computed once and by halving: pool_2k(x) = pool_2(pool_k(x))
+    (the maximum over a window is the maximum over its sub-windows' maxima, ceil-mode borders included), so the
+    factor-4 and factor-8 skips read a map 4x / 16x smaller than the source, the encoder's own down-sampling and
+    the decoder's factor-2 skip share one tensor, and in backward every source receives ONE pooled gradient instead
+    of one per consumer.  Gradient routing: where a window holds several equal maxima the chain of 2x2 choices may
+    pick a different (equal) element than a single k x k scan; all-zero post-ReLU windows route to the first
+    element either way."""
+
+    def __init__(self, enc):
+        self.enc = enc
+        self.maps = {}
+
+    def get(self, src, k):
+        if k == 1:
+            return self.enc[src]
+        key = (src, k)
+        if key not in self.maps:
+            self.maps[key] = ops.max_pool_ceil(self.get(src, k // 2), 2)
+        return self.maps[key]
+
+
+def full_scale_decoder(m, enc, pools=None):
     """The UNet3+ full-scale skip decoder (modeling/UNet3p_SNws.py:127-156, UNet3p_res_ocr_SNws.py:327-361) over
     the encoder maps enc[1..5]; m holds convd{1..4}_cat, conv5_cat, convu_cat, conv_fusion.  Returns the finest
     decoder map.  Every up-sampled source goes through conv(upsample(x)) = sum_t up(W_t x): the 1x1 half
     Z = W_taps x is computed once per source at ITS resolution and shared by all the scales that consume it."""
     enc_cat = {1: m.convd1_cat, 2: m.convd2_cat, 3: m.convd3_cat, 4: m.convd4_cat}
+    if pools is None:
+        pools = PoolPyramid(enc)
     z5 = m.conv5_cat.taps(enc[5])
     zdec = {}
     dec = {}
@@ -154,7 +178,7 @@ def full_scale_decoder(m, enc):
         for src in (1, 2, 3, 4):
             out = buf[:, len(parts) * f:(len(parts) + 1) * f]
             if src < level:         # encoder map, max-pooled down to this level
-                parts.append(enc_cat[src](ops.max_pool_ceil(enc[src], 2 ** (level - src)), out=out))
+                parts.append(enc_cat[src](pools.get(src, 2 ** (level - src)), out=out))
             elif src == level:
                 parts.append(enc_cat[src](enc[src], out=out))
             else:                   # decoder map of a coarser level, up-sampled

@@ -54,7 +54,7 @@ def global_ce_loss(logits, target, ignore_index=255, group=None):
     t = target.long()
     ce_sum = F.cross_entropy(logits.float(), t, ignore_index=ignore_index, reduction="sum")
     cnt = torch.stack([(t != ignore_index).sum().to(torch.float32),
-                       torch.tensor(float(n), device=logits.device)])
+                       torch.full((), float(n), dtype=torch.float32, device=logits.device)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if cnt.is_cuda and dist.get_backend(group) == "gloo":
             h = cnt.cpu()
@@ -70,8 +70,10 @@ def global_ce_loss_fused(raw_logits, n_class, target, ignore_index=255, group=No
     soft-max, the loss and d(loss)/d(logits) are produced in one pass over the logits."""
     from . import ops
     n = raw_logits.shape[0]
+    # (torch.full is a device fill; torch.tensor(..., device=cuda) would be a blocking host-to-device copy that
+    # stalls the host until the forward pass has drained)
     cnt = torch.stack([(target.to(torch.int64) != ignore_index).sum().to(torch.float32),
-                       torch.tensor(float(n), device=raw_logits.device)])
+                       torch.full((), float(n), dtype=torch.float32, device=raw_logits.device)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if cnt.is_cuda and dist.get_backend(group) == "gloo":
             h = cnt.cpu()

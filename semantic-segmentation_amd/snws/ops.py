@@ -40,8 +40,11 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+PROFILE_ONLY = None     # optional tuple of tag prefixes: only those launches are bracketed (events cost host time)
+
+
 def _launch(tag, work, name, *args):
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and not tag.startswith(PROFILE_ONLY)):
         return L.call(name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
