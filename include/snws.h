@@ -174,11 +174,12 @@ int snws_sn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
  *
  * mode 0: copy, 1: max-pool factor k (window clipped at the border, out = ceil(in/k)), 2: bilinear up x k.
  * src (N,H,W,lds) C channels -> dst (N,OH,OW,ldd) written at the destination's channel slice (dst pointer already
- * offset).  bwd accumulates (+=) into dsrc, which the caller zeroes or reuses across consumers. */
+ * offset).  bwd with accumulate != 0 adds (+=) into dsrc, which the caller zeroes or reuses across consumers; with
+ * accumulate == 0 it writes every element of dsrc (no zero-fill needed). */
 int snws_resample_fwd(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int N, int H, int W, int C,
                       int mode, int k, void* stream);
 int snws_resample_bwd(const void* ddst, int64_t ldd, const void* src, int64_t lds, void* dsrc, int64_t ldds,
-                      int dtype, int N, int H, int W, int C, int mode, int k, void* stream);
+                      int dtype, int N, int H, int W, int C, int mode, int k, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution of a bilinearly up-sampled map without materialising it - replaces the pairs

@@ -74,7 +74,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void resample_bwd_window_kernel(const T* __restrict__ ddst, int64_t ldd,
                                                                   const T* __restrict__ src, int64_t lds_,
                                                                   T* __restrict__ dsrc, int64_t ldds, int N, int H,
-                                                                  int W, int OH, int OW, int C, int mode, int k) {
+                                                                  int W, int OH, int OW, int C, int mode, int k, int accumulate) {
   const int CG = C / V;
   const int64_t total = (int64_t)N * OH * OW * CG;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -89,10 +89,14 @@ __global__ __launch_bounds__(256) void resample_bwd_window_kernel(const T* __res
     if (mode == MODE_COPY) {
       float a[V];
       T* q = dn + ((int64_t)oy * W + ox) * ldds;
-      Vec<T, V>::load(q, a);
+      if (accumulate) {
+        Vec<T, V>::load(q, a);
 #pragma unroll
-      for (int v = 0; v < V; ++v) a[v] += g[v];
-      Vec<T, V>::store(q, a);
+        for (int v = 0; v < V; ++v) a[v] += g[v];
+        Vec<T, V>::store(q, a);
+      } else {
+        Vec<T, V>::store(q, g);
+      }
       continue;
     }
     const T* sn = src + (int64_t)n * H * W * lds_ + (int64_t)cg * V;
@@ -117,12 +121,17 @@ __global__ __launch_bounds__(256) void resample_bwd_window_kernel(const T* __res
         bool any = false;
 #pragma unroll
         for (int v = 0; v < V; ++v) any |= (arg[v] == pos);
-        if (!any) continue;
         float a[V];
         T* q = dn + ((int64_t)yy * W + xx) * ldds;
-        Vec<T, V>::load(q, a);
+        if (accumulate) {
+          if (!any) continue;
+          Vec<T, V>::load(q, a);
 #pragma unroll
-        for (int v = 0; v < V; ++v) a[v] += (arg[v] == pos) ? g[v] : 0.f;
+          for (int v = 0; v < V; ++v) a[v] += (arg[v] == pos) ? g[v] : 0.f;
+        } else {      // every source pixel belongs to exactly one window: write the whole gradient, zeros included
+#pragma unroll
+          for (int v = 0; v < V; ++v) a[v] = (arg[v] == pos) ? g[v] : 0.f;
+        }
         Vec<T, V>::store(q, a);
       }
   }
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void resample_bwd_window_kernel(const T* __res
 template <typename T, int V>
 __global__ __launch_bounds__(256) void resample_bwd_bilinear_kernel(const T* __restrict__ ddst, int64_t ldd,
                                                                     T* __restrict__ dsrc, int64_t ldds, int N, int H,
-                                                                    int W, int OH, int OW, int C, int k) {
+                                                                    int W, int OH, int OW, int C, int k, int accumulate) {
   const int CG = C / V;
   const int64_t total = (int64_t)N * H * W * CG;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -172,10 +181,14 @@ __global__ __launch_bounds__(256) void resample_bwd_bilinear_kernel(const T* __r
     }
     float a[V];
     T* q = dsrc + (((int64_t)n * H + iy) * W + ix) * ldds + (int64_t)cg * V;
-    Vec<T, V>::load(q, a);
+    if (accumulate) {
+      Vec<T, V>::load(q, a);
 #pragma unroll
-    for (int v = 0; v < V; ++v) a[v] += acc[v];
-    Vec<T, V>::store(q, a);
+      for (int v = 0; v < V; ++v) a[v] += acc[v];
+      Vec<T, V>::store(q, a);
+    } else {
+      Vec<T, V>::store(q, acc);
+    }
   }
 }
 
@@ -206,14 +219,14 @@ int run_fwd(const void* src, int64_t lds_, void* dst, int64_t ldd, int N, int H,
 
 template <typename T, int V>
 int run_bwd(const void* ddst, int64_t ldd, const void* src, int64_t lds_, void* dsrc, int64_t ldds, int N, int H, int W,
-            int C, int mode, int k, hipStream_t st) {
+            int C, int mode, int k, int accumulate, hipStream_t st) {
   const int OH = out_size(H, mode, k), OW = out_size(W, mode, k);
   if (mode == MODE_BILINEAR) {
     const int64_t total = (int64_t)N * H * W * (C / V);
-    resample_bwd_bilinear_kernel<T, V><<<grid_for(total), 256, 0, st>>>((const T*)ddst, ldd, (T*)dsrc, ldds, N, H, W, OH, OW, C, k);
+    resample_bwd_bilinear_kernel<T, V><<<grid_for(total), 256, 0, st>>>((const T*)ddst, ldd, (T*)dsrc, ldds, N, H, W, OH, OW, C, k, accumulate);
   } else {
     const int64_t total = (int64_t)N * OH * OW * (C / V);
-    resample_bwd_window_kernel<T, V><<<grid_for(total), 256, 0, st>>>((const T*)ddst, ldd, (const T*)src, lds_, (T*)dsrc, ldds, N, H, W, OH, OW, C, mode, k);
+    resample_bwd_window_kernel<T, V><<<grid_for(total), 256, 0, st>>>((const T*)ddst, ldd, (const T*)src, lds_, (T*)dsrc, ldds, N, H, W, OH, OW, C, mode, k, accumulate);
   }
   SNWS_LAUNCH_CHECK("snws_resample_bwd");
   return SNWS_OK;
@@ -245,7 +258,7 @@ extern "C" int snws_resample_fwd(const void* src, int64_t lds_, void* dst, int64
 }
 
 extern "C" int snws_resample_bwd(const void* ddst, int64_t ldd, const void* src, int64_t lds_, void* dsrc, int64_t ldds,
-                                 int dtype, int N, int H, int W, int C, int mode, int k, void* stream) {
+                                 int dtype, int N, int H, int W, int C, int mode, int k, int accumulate, void* stream) {
   if (int rc = check("snws_resample_bwd", dtype, N, H, W, C, mode, k)) return rc;
   SNWS_CHECK_ARG(ddst && dsrc && ldd >= C && ldds >= C, "snws_resample_bwd: NULL pointer or pixel stride < C");
   SNWS_CHECK_ARG(mode != MODE_MAXPOOL || (src && lds_ >= C), "snws_resample_bwd: max-pool backward needs the source");
@@ -253,10 +266,10 @@ extern "C" int snws_resample_bwd(const void* ddst, int64_t ldd, const void* src,
   const bool src_ok = mode != MODE_MAXPOOL || (al16(src));
   if (dtype == SNWS_F32) {
     if (C % 4 == 0 && ldd % 4 == 0 && ldds % 4 == 0 && (mode != MODE_MAXPOOL || lds_ % 4 == 0) && al16(ddst) && al16(dsrc) && src_ok)
-      return run_bwd<float, 4>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, st);
-    return run_bwd<float, 1>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, st);
+      return run_bwd<float, 4>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, accumulate, st);
+    return run_bwd<float, 1>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, accumulate, st);
   }
   if (C % 8 == 0 && ldd % 8 == 0 && ldds % 8 == 0 && (mode != MODE_MAXPOOL || lds_ % 8 == 0) && al16(ddst) && al16(dsrc) && src_ok)
-    return run_bwd<bf16_t, 8>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, st);
-  return run_bwd<bf16_t, 1>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, st);
+    return run_bwd<bf16_t, 8>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, accumulate, st);
+  return run_bwd<bf16_t, 1>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, accumulate, st);
 }

@@ -700,10 +700,10 @@ class ResampleFn(torch.autograd.Function):
         m, k, (N, C, H, W), ld = ctx.meta
         (xs,) = ctx.saved_tensors
         dys, ldd = as_nhwc(dy)
-        dx = torch.zeros((N, H, W, C), dtype=dys.dtype, device=dys.device).permute(0, 3, 1, 2)
+        dx = new_nhwc(N, C, H, W, dys.dtype, dys.device)      # written in full by the kernel (accumulate = 0)
         OH, OW = dy.shape[2], dy.shape[3]
         _launch("resample_bwd", float(dys.element_size()) * N * C * (H * W + OH * OW), "snws_resample_bwd", _ptr(dys),
-                ldd, _ptr(xs), ld, _ptr(dx), C, dtype_code(dys), N, H, W, C, m, k, _stream())
+                ldd, _ptr(xs), ld, _ptr(dx), C, dtype_code(dys), N, H, W, C, m, k, 0, _stream())
         return dx, None, None
 
 
