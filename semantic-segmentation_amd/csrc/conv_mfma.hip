@@ -931,7 +931,14 @@ extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, cons
   a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
   a.coTiles = cdiv(d->C_out, 64); a.ciTiles = c64 ? cdiv(d->C_in, 64) : 1;
   const int ntiles = d->N * a.tilesX * a.tilesY, npairs = a.coTiles * a.ciTiles;
-  int splits = cdiv(2048, npairs);
+  // Every workgroup ends with a 64x64x9 float-atomic flush (147 KB; the chip retires ~1.3 TB/s of atomics), so a
+  // launch wants few, long workgroups: one resident round (256 CUs x 2) unless each workgroup of a 2048-wide launch
+  // would still sweep >= 32 pixel tiles - then the finer split balances better than it costs.  (Measured: 64->64 @512^2
+  // 650 -> 813 TFLOP/s, 128->128 @256^2 703 -> 924 with one round; 320->320 @512^2 prefers 2048: 1057 vs 981.)
+  static const int forced_blocks = getenv("SNWS_WGRAD_BLOCKS") ? atoi(getenv("SNWS_WGRAD_BLOCKS")) : 0;
+  const int target_blocks = forced_blocks > 0 ? forced_blocks : ((int64_t)ntiles * npairs >= 32ll * 2048 ? 2048 : 512);
+  int splits = target_blocks >= 2048 ? cdiv(target_blocks, npairs) : target_blocks / npairs;
+  if (splits < 1) splits = 1;
   if (splits > ntiles) splits = ntiles;
   a.tilesPerSplit = cdiv(ntiles, splits);
   splits = cdiv(ntiles, a.tilesPerSplit);
