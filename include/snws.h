@@ -223,6 +223,15 @@ int snws_argmax_stitch(const void* logits, int dtype, int64_t ld, int h, int w, 
                        int y0, int x0, int remap_background, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused AdamW over a flat float32 buffer - replaces torch.optim.AdamW(model.parameters(), lr, weight_decay)
+ * (train.py:81) stepped once per iteration (train.py:254); `lr` is the poly-schedule value of that iteration
+ * (utils/lr_scheduler.py:43-70).  param/grad/exp_avg/exp_avg_sq: n floats each, 16-byte aligned; step >= 1 is the
+ * 1-based update count (bias correction); the gradient is read as grad * grad_scale.  In place. */
+int snws_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Collectives for hosts without their own - the exchange points of the data-parallel path as in-place all-reduces
  * over RCCL, loaded at run time.  Replaces the SyncMaster / SlavePipe rendez-vous of
  * modeling/sync_batchnorm/comm.py:39-43,71-90 (SwitchNorm / BN statistics: the `pack` buffers of snws_sn_mix_a and

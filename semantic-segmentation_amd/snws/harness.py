@@ -94,9 +94,13 @@ class GradBuckets:
     finish() waits and copies the sums back.  Parameters that received no gradient (unused modules) are skipped
     consistently on every rank because usage is data-independent."""
 
-    def __init__(self, params, bucket_mb=25.0, group=None):
+    def __init__(self, params, bucket_mb=25.0, group=None, flat_grad=None, flat_offsets=None):
+        """flat_grad / flat_offsets: the flat gradient buffer of snws.optim.FlatAdamW and each parameter's offset in
+        it; a bucket is then a contiguous slice that is all-reduced in place (no flatten / unflatten copies)."""
         self.group = group
         self.params = [p for p in params if p.requires_grad]
+        self.flat_grad = flat_grad
+        self.slices = None
         self.buckets = []
         cur, size = [], 0
         for p in reversed(self.params):
@@ -111,6 +115,13 @@ class GradBuckets:
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self.where[p] = bi
+        if flat_grad is not None:
+            index = {p: i for i, p in enumerate(self.params)}
+            ends = list(flat_offsets[1:]) + [flat_grad.numel()]
+            self.slices = []
+            for b in self.buckets:           # reverse registration order: b[-1] has the lowest offset
+                lo, hi = index[b[-1]], index[b[0]]
+                self.slices.append((flat_offsets[lo], ends[hi]))
         self.pending = [0] * len(self.buckets)
         self.work = []
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -124,11 +135,22 @@ class GradBuckets:
         self.work = []
 
     def _launch(self, bi):
+        from . import ops
+        if self.slices is not None:
+            lo, hi = self.slices[bi]
+            flat = self.flat_grad[lo:hi]
+            ops.trace_collective("bucket%d" % bi, flat.numel())
+            if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+                host = flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(host)
+                return
+            self.work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, ()))
+            return
         ps = [p for p in self.buckets[bi] if p.grad is not None]
         if not ps:
             return
         flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
-        from . import ops
         ops.trace_collective("bucket%d" % bi, flat.numel())
         if flat.is_cuda and dist.get_backend(self.group) == "gloo":   # test vehicle: reduce on the host, synchronously
             host = flat.cpu()
@@ -166,18 +188,25 @@ class Trainer:
     """One-replica training driver with the reference's hyper-parameters as defaults (train.py:384-429)."""
 
     def __init__(self, model, lr=0.002, weight_decay=5e-4, total_iters=1000, ignore_index=255, group=None,
-                 bucket_mb=25.0, fused_loss=None):
+                 bucket_mb=25.0, fused_loss=None, optimizer="flat"):
         self.model = model
         # classes = output channels of the last registered 1x1 classification conv the forward uses
         head = getattr(model, "cls_head", None) or getattr(model, "output_seg_map")
         self.n_class = head.out_channels
         self.fused_loss = hasattr(model, "raw_logits") if fused_loss is None else bool(fused_loss)
         self.base_lr, self.total_iters, self.ignore_index, self.group = lr, total_iters, ignore_index, group
-        try:
-            self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, fused=True)
-        except (RuntimeError, TypeError):
-            self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
-        self.buckets = GradBuckets(list(model.parameters()), bucket_mb, group)
+        if optimizer == "flat":      # one fused launch over flat parameter / gradient buffers (snws.optim)
+            from .optim import FlatAdamW
+            self.opt = FlatAdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+        else:                        # torch's multi-tensor AdamW
+            try:
+                self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, fused=True)
+            except (RuntimeError, TypeError):
+                self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+        if optimizer == "flat":
+            self.buckets = GradBuckets(self.opt.params, bucket_mb, group, self.opt.flat_g, self.opt.offsets)
+        else:
+            self.buckets = GradBuckets(list(model.parameters()), bucket_mb, group)
         self.it = 0
         from . import ops
         ops.CACHE_FILTERS = True        # this driver owns the weights: it announces every update below

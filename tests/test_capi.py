@@ -129,3 +129,31 @@ def test_tile_offsets_match_golden():
         args = [int(v) for v in g["tiles%d_args" % i]]
         assert np.array_equal(np.array(tiles.gen_tiles_offs(*args), np.int64), g["tiles%d" % i])
     assert len(tiles.gen_tiles_offs(2748, 2748, 512, 0)) == 36
+
+
+def test_saver_layout_and_checkpoint_format(tmp_path):
+    """snws.checkpoint.Saver reproduces the run-directory layout of utils/saver.py:11-47 and the checkpoint dict of
+    train.py:272-277; a DataParallel-style 'module.' prefix is accepted on load."""
+    from snws import checkpoint
+    net = torch.nn.Sequential(torch.nn.Linear(3, 2))
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    root = str(tmp_path / "run")
+    s0 = checkpoint.Saver("cloud", "unet3p", root=root)
+    f0 = s0.save_checkpoint(net, opt, epoch=1, best_pred=0.5, is_best=True)
+    assert f0.endswith(os.path.join("cloud", "unet3p", "experiment_0", "checkpoint.pth.tar"))
+    assert open(os.path.join(os.path.dirname(f0), "best_pred.txt")).read() == "0.5"
+    assert os.path.exists(os.path.join(root, "cloud", "unet3p", "model_best.pth.tar"))
+    s1 = checkpoint.Saver("cloud", "unet3p", root=root)
+    assert s1.experiment_dir.endswith("experiment_1")
+    s1.save_checkpoint(net, opt, epoch=2, best_pred=0.4, is_best=True)       # does not beat run 0: best file unchanged
+    best = torch.load(os.path.join(root, "cloud", "unet3p", "model_best.pth.tar"), weights_only=True)
+    assert best["epoch"] == 1 and best["best_pred"] == 0.5
+    ck = torch.load(f0, weights_only=True)
+    ck["state_dict"] = {"module." + k: v for k, v in ck["state_dict"].items()}
+    p2 = str(tmp_path / "dp.pth.tar")
+    torch.save(ck, p2)
+    net2 = torch.nn.Sequential(torch.nn.Linear(3, 2))
+    epoch, bp = checkpoint.load_checkpoint(p2, net2, None)
+    assert (epoch, bp) == (1, 0.5) and torch.equal(net2[0].weight, net[0].weight)
+    with pytest.raises(RuntimeError):
+        checkpoint.load_checkpoint(str(tmp_path / "missing.pth.tar"), net2)

@@ -886,3 +886,77 @@ np.savez(sys.argv[1], **out)
     for key in res[0]:
         a, b = res[0][key], res[1][key]
         assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max(), key
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """snws.optim.FlatAdamW == torch.optim.AdamW step for step (decoupled decay, bias correction), including a
+    parameter that never receives a gradient (left untouched, as torch does), and the two exchange state_dicts."""
+    from snws.optim import FlatAdamW
+    torch.manual_seed(8)
+    shapes = [(7, 3, 3, 3), (7,), (1, 5, 1, 1), (3,), (10, 7, 1, 1), (2,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = torch.optim.AdamW(pa, lr=2e-3, weight_decay=5e-4)
+    ob = FlatAdamW(pb, lr=2e-3, weight_decay=5e-4)
+    for it in range(6):
+        lr = 2e-3 * (1 - it / 10.0) ** 0.9
+        oa.param_groups[0]["lr"] = lr
+        ob.param_groups[0]["lr"] = lr
+        oa.zero_grad(set_to_none=True)
+        ob.zero_grad()
+        ws_ = [torch.randn(s, device=DEV) for s in shapes]
+        la = sum((p * w).sum() + (p * p).sum() for p, w in zip(pa[:-1], ws_))     # the last parameter is unused
+        lb = sum((p * w).sum() + (p * p).sum() for p, w in zip(pb[:-1], ws_))
+        la.backward()
+        lb.backward()
+        oa.step()
+        ob.step()
+        if it == 2:      # hand the state over in both directions mid-run
+            sa, sb = oa.state_dict(), ob.state_dict()
+            assert set(sb["state"].keys()) == set(sa["state"].keys())
+            ob.load_state_dict(sa)
+            oa.load_state_dict(sb)
+    for a, b in zip(pa, pb):
+        assert relerr(b, a) < 2e-6
+    assert torch.equal(pb[-1], pa[-1])
+    sd = ob.state_dict()
+    assert 5 not in sd["state"] and float(sd["state"][0]["step"]) == 6.0
+
+
+def test_trainer_flat_optimizer_matches_torch_optimizer(tmp_path):
+    """Three Trainer steps with the flat fused AdamW equal three steps with torch's AdamW; the checkpoint written after
+    them (reference format) restores model, optimizer and counters into a fresh Trainer that then continues
+    identically."""
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from snws import harness, checkpoint
+    img, lab = patterns.synth_batch(2, 14, 64, 101)
+    img, lab = img.to(DEV), lab.to(DEV)
+    models = []
+    for kind in ("torch", "flat"):
+        model = UNet3p_SNws(14, 4, 10, 1, 1)
+        patterns.det_init(model)
+        model = model.to(DEV)
+        tr = harness.Trainer(model, optimizer=kind, total_iters=50)
+        for _ in range(3):
+            tr.step(img, lab)
+        models.append((model, tr))
+    for (n, a), (_, b) in zip(models[0][0].named_parameters(), models[1][0].named_parameters()):
+        # Adam moves every element by ~lr per step whatever the gradient's size, so float32 noise in a near-zero
+        # gradient shows up as a difference of the order of lr * steps = 6e-3 (absolute; weights are O(0.5))
+        assert float((a - b).abs().max()) < 8e-3, n
+    model, tr = models[1]
+    path = str(tmp_path / "checkpoint.pth.tar")
+    checkpoint.save_checkpoint(path, model, tr.opt, epoch=7, best_pred=0.625)
+    ck = torch.load(path, weights_only=True)
+    assert set(ck.keys()) == {"epoch", "state_dict", "optimizer", "best_pred"}
+    assert list(ck["state_dict"].keys()) == list(model.state_dict().keys())
+    fresh = UNet3p_SNws(14, 4, 10, 1, 1).to(DEV)
+    tr2 = harness.Trainer(fresh, optimizer="flat", total_iters=50)
+    epoch, best = checkpoint.load_checkpoint(path, fresh, tr2.opt)
+    tr2.it = tr.it
+    assert (epoch, best) == (7, 0.625)
+    l1 = float(tr.step(img, lab))
+    l2 = float(tr2.step(img, lab))
+    assert abs(l1 - l2) <= 1e-5 * abs(l1)
+    for (n, a), (_, b) in zip(model.named_parameters(), fresh.named_parameters()):
+        assert relerr(b, a) < 1e-5, n
