@@ -189,9 +189,17 @@ def main():
         if fam:
             fl, tt, cnt = sum(v[1] for v in fam), sum(v[2] for v in fam), sum(v[0] for v in fam)
             ach = fl / tt / 1e12
+            # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the
+            # committed summary of the rocprofv3 --pmc passes over this same command (tools/run_pmc_bench.sh)
+            traffic, tsrc = None, None
+            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_bench_conv.json")
+            if args.model == "unet3p" and args.batch == 16 and args.size == 512 and args.filters == 64 and os.path.exists(pmc_file):
+                with open(pmc_file) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                tsrc = "profiles/r01_pmc_bench_conv.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             roofline = {"bound": "mfma", "kernel": "conv_fwd_kernel<KC=32,TAPS=9> (forward + dgrad launches)",
                         "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launches": cnt,
+                        "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "launches": cnt,
                         "avg_launch_ms": tt / cnt * 1e3, "flops_per_launch": fl / cnt}
         summary = {}
         for tag, (cnt, work, tt) in sorted(kernels.items()):
