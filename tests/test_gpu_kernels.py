@@ -94,6 +94,35 @@ def test_evaluator_many_classes_and_unaligned():
     assert np.array_equal(ev._matrix(), O.confusion_matrix(gt.reshape(-1)[1:], pr.reshape(-1)[1:], 64).astype(np.float64))
 
 
+def test_evaluator_edge_inputs():
+    """Empty batch, all-ignored labels (255 / -1 / NaN), label and prediction dtypes other than f32 / i64, and the
+    shape-mismatch assertion of utils/metrics.py:48 - each against the oracle's restatement of _generate_matrix."""
+    from utils.metrics import Evaluator
+    ev = Evaluator(10)
+    ev.add_batch(np.zeros((0, 4, 4), np.float32), np.zeros((0, 4, 4), np.int64))          # nothing to count
+    assert ev.confusion_matrix.sum() == 0
+    ign = np.array([[255.0, -1.0, np.nan, 10.0, 300.0]], np.float32).reshape(1, 1, 5)
+    ev.add_batch(ign, np.zeros((1, 1, 5), np.int64))
+    assert ev._matrix().sum() == 0
+    rng = np.random.default_rng(11)
+    for gdt, pdt in ((np.uint8, np.int32), (np.int64, np.uint8), (np.float64, np.int64), (np.int32, np.int64)):
+        gt = rng.integers(0, 12, size=(2, 19, 23)).astype(gdt)          # 10, 11 are outside the class range: ignored
+        pr = rng.integers(0, 10, size=(2, 19, 23)).astype(pdt)
+        e2 = Evaluator(10)
+        e2.add_batch(gt, pr)
+        assert np.array_equal(e2._matrix(), O.confusion_matrix(gt, pr, 10).astype(np.float64)), (gdt, pdt)
+    with pytest.raises(AssertionError):
+        ev.add_batch(np.zeros((1, 4, 4), np.float32), np.zeros((1, 4, 5), np.int64))
+    # accumulation over calls and reset()
+    e3 = Evaluator(3)
+    a, b = np.array([[0.0, 1.0, 2.0, 2.0]], np.float32), np.array([[0, 1, 1, 2]], np.int64)
+    e3.add_batch(a, b)
+    e3.add_batch(a, b)
+    assert np.array_equal(e3._matrix(), 2 * O.confusion_matrix(a, b, 3))
+    e3.reset()
+    assert e3._matrix().sum() == 0
+
+
 def test_evaluator_out_of_range_prediction_raises():
     from utils.metrics import Evaluator
     ev = Evaluator(10)
