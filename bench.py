@@ -134,6 +134,7 @@ def main():
     from modeling.UNet3p_res_ocr_SNws import UNet3p_res_ocr_SNws
 
     rank, world, device = harness.init_distributed()
+    grouped = dist.is_initialized()      # world > 1, or a one-rank self-test group
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if world != args.gpus:
@@ -143,7 +144,7 @@ def main():
     cls = UNet3p_SNws if args.model == "unet3p" else UNet3p_res_ocr_SNws
     model = cls(14, args.filters, 10, 1, 1).to(device)
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if world > 1:   # identical replicas
+    if grouped:   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     trainer = harness.Trainer(model, lr=0.002, weight_decay=5e-4, total_iters=max(1000, args.steps + args.warmup))
@@ -151,7 +152,7 @@ def main():
                                        dtype=model.compute_dtype)
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,11 +168,11 @@ def main():
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if grouped:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     loss_val = float(loss)
-    if world > 1:
+    if grouped:
         lt = loss.clone()
         dist.all_reduce(lt)
         loss_val = float(lt)
@@ -225,7 +226,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model == "unet3p":
             out["cpu_baseline"] = cpu_baseline(args.filters, args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -31,13 +31,19 @@ def init_distributed():
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    # SNWS_DP_SELFTEST=1: a one-rank group, so a single-GPU box exercises every collective of the multi-GPU path
+    if (world > 1 or os.environ.get("SNWS_DP_SELFTEST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, device
+
+
+def _dp(group=None):
+    from . import ops
+    return ops.dp_collectives(group)
 
 
 def poly_lr(base_lr, it, total_iters):
@@ -55,7 +61,7 @@ def global_ce_loss(logits, target, ignore_index=255, group=None):
     ce_sum = F.cross_entropy(logits.float(), t, ignore_index=ignore_index, reduction="sum")
     cnt = torch.stack([(t != ignore_index).sum().to(torch.float32),
                        torch.full((), float(n), dtype=torch.float32, device=logits.device)])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _dp(group):
         if cnt.is_cuda and dist.get_backend(group) == "gloo":
             h = cnt.cpu()
             dist.all_reduce(h, group=group)
@@ -74,7 +80,7 @@ def global_ce_loss_fused(raw_logits, n_class, target, ignore_index=255, group=No
     # stalls the host until the forward pass has drained)
     cnt = torch.stack([(target.to(torch.int64) != ignore_index).sum().to(torch.float32),
                        torch.full((), float(n), dtype=torch.float32, device=raw_logits.device)])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _dp(group):
         if cnt.is_cuda and dist.get_backend(group) == "gloo":
             h = cnt.cpu()
             dist.all_reduce(h, group=group)
@@ -124,7 +130,7 @@ class GradBuckets:
                 self.slices.append((flat_offsets[lo], ends[hi]))
         self.pending = [0] * len(self.buckets)
         self.work = []
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = _dp(group)
         if self.enabled:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)

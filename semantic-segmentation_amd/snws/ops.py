@@ -273,6 +273,16 @@ def trace_collective(kind, numel):
             f.write("%s %d\n" % (kind, numel))
 
 
+def dp_collectives(group=None):
+    """True when the data-parallel collectives have to be issued: a process group of more than one rank - or of one
+    rank when SNWS_DP_SELFTEST=1, which lets a single-GPU box drive every RCCL call of the multi-GPU path."""
+    import os
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("SNWS_DP_SELFTEST") == "1"
+
+
 def sync_world(group=None):
     """Number of data-parallel ranks whose BN-branch statistics are summed (1 when not distributed)."""
     import torch.distributed as dist
@@ -325,8 +335,9 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     L.call("snws_sn_finalize", _ptr(stat_part), T, _ptr(stat_shift), per_image, N, HW, C, _ptr(ctx), st)
     pack = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
     L.call("snws_sn_mix_a", _ptr(ctx), _ptr(pack), N, C, st)
-    world = sync_world(p.group) if (p.sync and p.training and p.using_bn) else 1
-    if world > 1:
+    synced = p.sync and p.training and p.using_bn and dp_collectives(p.group)
+    world = sync_world(p.group) if synced else 1
+    if synced:
         _allreduce_sum(pack, p.group)
     gamma, beta = _f32c(p.gamma).view(-1), _f32c(p.beta).view(-1)
     mw, vw = _f32c(p.mean_weight), _f32c(p.var_weight)
@@ -352,7 +363,7 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
             dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
     n_global = float(N * world) if world > 1 else float(N)
     saved = dict(xs=xs, ldx=ldx, ctx=ctx, gamma=gamma, beta=beta, mw=mw, vw=vw, relu=bool(relu), shape=(N, C, H, W),
-                 training=p.training, using_bn=p.using_bn, world=world, group=p.group, n_global=n_global,
+                 training=p.training, using_bn=p.using_bn, world=world, synced=synced, group=p.group, n_global=n_global,
                  y=(y if residual is not None and relu else None))
     return y, saved
 
@@ -382,7 +393,7 @@ def sn_backward(dy, s, want_dx_sum=False):
     dbeta = torch.empty(C, dtype=torch.float32, device=dev)
     L.call("snws_sn_bwd_mix_a", _ptr(part), T, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(ctxb), _ptr(packb), _ptr(dgamma),
            _ptr(dbeta), N, C, st)
-    if s["world"] > 1:
+    if s["synced"]:
         _allreduce_sum(packb, s["group"])
     K = s["mw"].numel()
     dmw = torch.empty(K, dtype=torch.float32, device=dev)

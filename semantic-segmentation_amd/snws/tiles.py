@@ -52,6 +52,7 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
     world, rank = 1, 0
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+    merge = ops.dp_collectives(group)
     if n_class is None:
         head = getattr(model, "cls_head", None) or getattr(model, "output_seg_map")
         n_class = head.out_channels
@@ -62,7 +63,7 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
         model.raw_logits = True
     mine = [(i, o) for i, o in enumerate(offs) if i % world == rank]
     pred = torch.zeros((H, W), dtype=torch.int64, device=disk.device)
-    tile_pred = torch.empty((block, block), dtype=torch.int64, device=disk.device) if world > 1 else None
+    tile_pred = torch.empty((block, block), dtype=torch.int64, device=disk.device) if merge else None
     try:
         for b0 in range(0, len(mine), tiles_per_forward):
             chunk = mine[b0:b0 + tiles_per_forward]
@@ -71,7 +72,7 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
                 batch = normalize(batch)
             logits = model(batch)
             for j, (i, (x, y)) in enumerate(chunk):
-                if world == 1:      # list order: a later tile overwrites an earlier one
+                if not merge:       # list order: a later tile overwrites an earlier one
                     ops.argmax_stitch(logits[j:j + 1], n_class, pred, y, x, remap_background)
                 else:               # key = (tile index + 1) * 256 + class: max over ranks = the LAST tile in list order
                     ops.argmax_stitch(logits[j:j + 1], n_class, tile_pred, 0, 0, remap_background)
@@ -81,7 +82,7 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
         model.train(was_training)
         if raw:
             model.raw_logits = False
-    if world > 1:
+    if merge:
         if dist.get_backend(group) == "gloo":     # CPU-side test vehicle: stage through host memory
             h = pred.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)

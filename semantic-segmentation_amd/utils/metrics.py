@@ -84,7 +84,8 @@ class Evaluator(object):
         c = self._counts
         if all_reduce:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            from snws import ops
+            if ops.dp_collectives(group):
                 if dist.get_backend(group) == "gloo":
                     c = c.cpu()
                 dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
