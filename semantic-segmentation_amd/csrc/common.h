@@ -87,6 +87,33 @@ struct Vec<bf16_t, 8> {
     *reinterpret_cast<uint4*>(p) = v;
   }
 };
+// streaming variants: non-temporal 16-byte accesses for tensors that are read or written exactly once per kernel
+template <typename T, int V>
+struct VecNT {
+  static __device__ __forceinline__ void load(const T* p, float (&f)[V]) { Vec<T, V>::load(p, f); }
+  static __device__ __forceinline__ void store(T* p, const float (&f)[V]) { Vec<T, V>::store(p, f); }
+};
+typedef unsigned int snws_u32x4 __attribute__((ext_vector_type(4)));
+template <>
+struct VecNT<bf16_t, 8> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&f)[8]) {
+    const snws_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const snws_u32x4*>(p));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(v[i] << 16);
+      f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&f)[8]) {
+    snws_u32x4 v;
+    v[0] = pack_bf16x2(f[0], f[1]);
+    v[1] = pack_bf16x2(f[2], f[3]);
+    v[2] = pack_bf16x2(f[4], f[5]);
+    v[3] = pack_bf16x2(f[6], f[7]);
+    __builtin_nontemporal_store(v, reinterpret_cast<snws_u32x4*>(p));
+  }
+};
+
 template <>
 struct Vec<bf16_t, 1> {
   static __device__ __forceinline__ void load(const bf16_t* p, float (&f)[1]) { f[0] = (float)(*p); }

@@ -285,11 +285,11 @@ __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restric
     for (; p + 3 * m.PR < p1; p += 4 * m.PR) {
       float a[4][V];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) Vec<T, V>::load(xn + (p + u * m.PR) * ldx + co, a[u]);
+      for (int u = 0; u < 4; ++u) VecNT<T, V>::load(xn + (p + u * m.PR) * ldx + co, a[u]);
       float r[4][V];
       if (RES) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Vec<T, V>::load(rn + (p + u * m.PR) * ldr + co, r[u]);
+        for (int u = 0; u < 4; ++u) VecNT<T, V>::load(rn + (p + u * m.PR) * ldr + co, r[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -299,20 +299,20 @@ __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restric
           if (RES) z += r[u][v];
           a[u][v] = RELU ? fmaxf(z, 0.f) : z;
         }
-        Vec<T, V>::store(yn + (p + u * m.PR) * ldy + co, a[u]);
+        VecNT<T, V>::store(yn + (p + u * m.PR) * ldy + co, a[u]);
       }
     }
     for (; p < p1; p += m.PR) {
       float a[V], r[V];
-      Vec<T, V>::load(xn + p * ldx + co, a);
-      if (RES) Vec<T, V>::load(rn + p * ldr + co, r);
+      VecNT<T, V>::load(xn + p * ldx + co, a);
+      if (RES) VecNT<T, V>::load(rn + p * ldr + co, r);
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         float z = fmaf(a[v] - mu[v], sc[v], be[v]);
         if (RES) z += r[v];
         a[v] = RELU ? fmaxf(z, 0.f) : z;
       }
-      Vec<T, V>::store(yn + p * ldy + co, a);
+      VecNT<T, V>::store(yn + p * ldy + co, a);
     }
   }
 }
@@ -356,13 +356,13 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_reduce_kernel(const T* __re
       int64_t p = p0 + prow;
       for (; p + m.PR < p1; p += 2 * m.PR) {
         float a0[V], a1[V], g0[V], g1[V], y0[V], y1[V];
-        Vec<T, V>::load(xn + p * ldx + co, a0);
-        Vec<T, V>::load(xn + (p + m.PR) * ldx + co, a1);
-        Vec<T, V>::load(dn + p * lddy + co, g0);
-        Vec<T, V>::load(dn + (p + m.PR) * lddy + co, g1);
+        VecNT<T, V>::load(xn + p * ldx + co, a0);
+        VecNT<T, V>::load(xn + (p + m.PR) * ldx + co, a1);
+        VecNT<T, V>::load(dn + p * lddy + co, g0);
+        VecNT<T, V>::load(dn + (p + m.PR) * lddy + co, g1);
         if (YMASK) {
-          Vec<T, V>::load(yn + p * ldy + co, y0);
-          Vec<T, V>::load(yn + (p + m.PR) * ldy + co, y1);
+          VecNT<T, V>::load(yn + p * ldy + co, y0);
+          VecNT<T, V>::load(yn + (p + m.PR) * ldy + co, y1);
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -379,9 +379,9 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_reduce_kernel(const T* __re
       }
       for (; p < p1; p += m.PR) {
         float a0[V], g0[V], y0[V];
-        Vec<T, V>::load(xn + p * ldx + co, a0);
-        Vec<T, V>::load(dn + p * lddy + co, g0);
-        if (YMASK) Vec<T, V>::load(yn + p * ldy + co, y0);
+        VecNT<T, V>::load(xn + p * ldx + co, a0);
+        VecNT<T, V>::load(dn + p * lddy + co, g0);
+        if (YMASK) VecNT<T, V>::load(yn + p * ldy + co, y0);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           float e0 = a0[v] - mu[v];
@@ -597,13 +597,13 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
     int64_t p = p0 + prow;
     for (; p + m.PR < p1; p += 2 * m.PR) {
       float a0[V], a1[V], g0[V], g1[V], y0[V], y1[V];
-      Vec<T, V>::load(xn + p * ldx + co, a0);
-      Vec<T, V>::load(xn + (p + m.PR) * ldx + co, a1);
-      Vec<T, V>::load(dn + p * lddy + co, g0);
-      Vec<T, V>::load(dn + (p + m.PR) * lddy + co, g1);
+      VecNT<T, V>::load(xn + p * ldx + co, a0);
+      VecNT<T, V>::load(xn + (p + m.PR) * ldx + co, a1);
+      VecNT<T, V>::load(dn + p * lddy + co, g0);
+      VecNT<T, V>::load(dn + (p + m.PR) * lddy + co, g1);
       if (YMASK) {
-        Vec<T, V>::load(yn + p * ldy + co, y0);
-        Vec<T, V>::load(yn + (p + m.PR) * ldy + co, y1);
+        VecNT<T, V>::load(yn + p * ldy + co, y0);
+        VecNT<T, V>::load(yn + (p + m.PR) * ldy + co, y1);
       }
 #pragma unroll
       for (int v = 0; v < V; ++v) {
@@ -616,14 +616,14 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
         g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
         g1[v] = fmaf(sc[v], g1[v], fmaf(Bc[v], a1[v], Kc[v]));
       }
-      Vec<T, V>::store(on + p * lddx + co, g0);
-      Vec<T, V>::store(on + (p + m.PR) * lddx + co, g1);
+      VecNT<T, V>::store(on + p * lddx + co, g0);
+      VecNT<T, V>::store(on + (p + m.PR) * lddx + co, g1);
     }
     for (; p < p1; p += m.PR) {
       float a0[V], g0[V], y0[V];
-      Vec<T, V>::load(xn + p * ldx + co, a0);
-      Vec<T, V>::load(dn + p * lddy + co, g0);
-      if (YMASK) Vec<T, V>::load(yn + p * ldy + co, y0);
+      VecNT<T, V>::load(xn + p * ldx + co, a0);
+      VecNT<T, V>::load(dn + p * lddy + co, g0);
+      if (YMASK) VecNT<T, V>::load(yn + p * ldy + co, y0);
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         if (RELU) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
         }
         g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
       }
-      Vec<T, V>::store(on + p * lddx + co, g0);
+      VecNT<T, V>::store(on + p * lddx + co, g0);
     }
   }
 }
