@@ -169,6 +169,26 @@ int snws_sn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
                       int N, int64_t HW, int C, int relu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batch normalisation on the same streaming kernels - replaces nn.BatchNorm2d (+ nn.ReLU) of the OCR head
+ * (modeling/UNet3p_res_ocr_SNws.py:52-79,124,257,263) and _SynchronizedBatchNorm's statistics
+ * (modeling/sync_batchnorm/batchnorm.py:45-65,80-115).
+ *
+ * forward:  snws_sn_stats -> snws_sn_finalize -> snws_bn_pack -> [all-reduce pack over ranks: synchronised BN]
+ *           -> snws_bn_coeff -> snws_sn_apply(relu)
+ * backward: snws_sn_bwd_reduce -> snws_bn_bwd_pack (also gives d gamma, d beta of this rank) -> [all-reduce packb]
+ *           -> snws_bn_bwd_coeff -> snws_sn_bwd_apply
+ * pack  [2C+1]: sum_n mean_n(c), sum_n E_n[x^2](c), N     packb [2C]: sum dy'(c), sum dy'*xhat(c)
+ * snws_bn_coeff: mean / biased variance from pack (training) or the running buffers; inv_std = (var + eps)^-1/2, or
+ *   max(var, eps)^-1/2 with clamp_eps (batchnorm.py:104); running buffers (may be NULL) take momentum * the batch
+ *   mean / UNBIASED variance; gamma may be NULL (= 1).  count = global N*HW for snws_bn_bwd_coeff. */
+int snws_bn_pack(const float* ctx, int N, int64_t HW, int C, float* pack, void* stream);
+int snws_bn_coeff(float* ctx, const float* pack, const float* gamma, float* running_mean, float* running_var, int N,
+                  int64_t HW, int C, float eps, float momentum, int training, int clamp_eps, void* stream);
+int snws_bn_bwd_pack(const float* part, int T, int N, int C, float* packb, float* dgamma, float* dbeta, void* stream);
+int snws_bn_bwd_coeff(const float* ctx, float* ctxb, const float* packb, int N, int C, float count, int training,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Full-scale skip resampling - replaces nn.MaxPool2d(k,k,ceil_mode=True) / nn.Upsample(scale, bilinear,
  * align_corners=False) / torch.cat at modeling/UNet3p_SNws.py:49-55,127-156 and their autograd.
  *

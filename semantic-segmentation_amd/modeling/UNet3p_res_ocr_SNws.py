@@ -4,9 +4,9 @@ shapes and registration order (a reference checkpoint loads with load_state_dict
 
 What runs where: every Conv2dws -> SwitchNorm2d -> ReLU block, the residual blocks' conv + SwitchNorm + add + ReLU,
 the full-scale skip decoder and all plain nn.Conv2d layers (1x1 and the 320 -> 512 3x3) go through the library's
-HIP kernels.  The OCR head's BatchNorm2d layers, its two soft-max + batched-matmul attention steps and Dropout2d are
-stock torch ops on the GPU (rocBLAS / elementwise), as plain library work.  BatchNorm2d uses the statistics of the
-local batch, as under the reference's DataParallel.
+HIP kernels, and so do the OCR head's BatchNorm2d + ReLU pairs (blocks.HipBatchNorm2d; statistics of the local
+batch, as under the reference's DataParallel).  Its two soft-max + batched-matmul attention steps and Dropout2d are
+stock torch ops on the GPU (rocBLAS / elementwise), as plain library work.
 """
 import torch
 import torch.nn as nn
@@ -16,7 +16,8 @@ from torch.nn.modules.utils import _pair
 
 import modeling.snorm as sn
 import modeling.weightstd as ws
-from modeling.blocks import (ConvSnRelu, PlainConv2d, PoolPyramid, Resnet_BasicBlock, crop_concat as CropConcat,  # noqa: F401
+from modeling.blocks import (ConvSnRelu, FusedAway, HipBatchNorm2d, PlainConv2d, PoolPyramid, Resnet_BasicBlock,  # noqa: F401
+                             crop_concat as CropConcat,
                              full_scale_decoder, head_conv, plain_conv, to_device_layout)
 from snws import ops
 
@@ -54,7 +55,8 @@ class _ObjectAttentionBlock(nn.Module):
         self.pool = nn.MaxPool2d(kernel_size=(scale, scale))
 
         def cbr(cin, cout):
-            return [PlainConv2d(cin, cout, kernel_size=1, stride=1, padding=0, bias=False), nn.BatchNorm2d(cout), nn.ReLU()]
+            return [PlainConv2d(cin, cout, kernel_size=1, stride=1, padding=0, bias=False),
+                    HipBatchNorm2d(cout, fuse_relu=True), FusedAway()]
         self.f_pixel = nn.Sequential(*(cbr(in_channels, key_channels) + cbr(key_channels, key_channels)))
         self.f_object = nn.Sequential(*(cbr(in_channels, key_channels) + cbr(key_channels, key_channels)))
         self.f_down = nn.Sequential(*cbr(in_channels, key_channels))
@@ -92,8 +94,8 @@ class SpatialOCR_Module(nn.Module):
         self.object_context_block = ObjectAttentionBlock2D(in_channels, key_channels, scale)
         self.conv_bn_dropout = nn.Sequential(
             PlainConv2d(2 * in_channels, out_channels, kernel_size=1, padding=0, bias=False),
-            nn.BatchNorm2d(out_channels),
-            nn.ReLU(),
+            HipBatchNorm2d(out_channels, fuse_relu=True),
+            FusedAway(),
             nn.Dropout2d(dropout))
 
     def forward(self, feats, proxy_feats):
@@ -141,13 +143,13 @@ class UNet3p_res_ocr_SNws(nn.Module):
         ocr_key_channels = 256
         self.aux_head = nn.Sequential(
             PlainConv2d(5 * f, 5 * f, kernel_size=1, stride=1, padding=0),
-            nn.BatchNorm2d(5 * f),
-            nn.ReLU(inplace=True),
+            HipBatchNorm2d(5 * f, fuse_relu=True),
+            FusedAway(),
             PlainConv2d(5 * f, n_class, kernel_size=1, stride=1, padding=0, bias=True))
         self.conv3x3_ocr = nn.Sequential(
             PlainConv2d(5 * f, ocr_mid_channels, kernel_size=3, stride=1, padding=1),
-            nn.BatchNorm2d(ocr_mid_channels),
-            nn.ReLU(inplace=True))
+            HipBatchNorm2d(ocr_mid_channels, fuse_relu=True),
+            FusedAway())
         self.ocr_gather_head = SpatialGather_Module(n_class)
         self.ocr_distri_head = SpatialOCR_Module(in_channels=ocr_mid_channels, key_channels=ocr_key_channels,
                                                  out_channels=ocr_mid_channels, scale=1, dropout=0.05)

@@ -107,6 +107,34 @@ class PlainConv2d(nn.Conv2d):
         return plain_conv(self, x)
 
 
+class HipBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state_dict keys) on the library's streaming kernels; with
+    fuse_relu the ReLU that follows it in the reference's Sequential runs in the same pass (put FusedAway() at the
+    ReLU's index to keep the Sequential numbering).  Statistics are those of the local batch (nn.BatchNorm2d under
+    the reference's DataParallel); sync_stats=True all-reduces them over the process group."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, fuse_relu=False,
+                 sync_stats=False, clamp_eps=False):
+        super(HipBatchNorm2d, self).__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.fuse_relu, self.sync_stats, self.clamp_eps = fuse_relu, sync_stats, clamp_eps
+        self.process_group = None
+
+    def forward(self, x):
+        self._check_input_dim(x)
+        ops.require_gpu(x, "BatchNorm2d")
+        momentum = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:       # cumulative moving average
+                momentum = 1.0 / float(self.num_batches_tracked)
+        return ops.BatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps,
+                                     self.training, self.fuse_relu, self.sync_stats, self.process_group, self.clamp_eps)
+
+
+class FusedAway(nn.Identity):
+    """Placeholder at the index of an activation that the preceding module already applied."""
+
+
 class Resnet_BasicBlock(nn.Module):
     """conv1-bn1-relu-conv2-bn2, += block input, relu (modeling/UNet3p_res_ocr_SNws.py:134-161) as two fused ops:
     ConvSnRelu and conv + SwitchNorm + residual add + ReLU."""

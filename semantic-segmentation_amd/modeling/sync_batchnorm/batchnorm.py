@@ -4,10 +4,11 @@ normalisation with the BIASED variance CLAMPED at eps (not +eps), running buffer
 variance and PyTorch's momentum convention.
 
 Synchronisation: one process per GPU; in training mode under an initialised torch.distributed group the packed
-[sum (C), ssum (C), size] vector is all-reduced (RCCL), forward and - through autograd - backward.  Outside a
-process group, or in eval mode, it is F.batch_norm like the reference's fallback (batchnorm.py:40-43).  Only
-DeepLab-style models use this class (modeling/deeplab.py:16-19); it is not on the SwitchNorm hot path and runs
-on stock torch element-wise ops."""
+per-channel moments are all-reduced (RCCL), forward and backward.  4-D GPU inputs (SynchronizedBatchNorm2d) run on
+the library's streaming kernels (snws_sn_stats / snws_bn_* / snws_sn_apply and their backward counterparts) with
+the clamp-at-eps inverse standard deviation in training and evaluation alike; 1-D / 3-D inputs and CPU tensors keep
+the composition of stock torch ops below (outside a process group, or in eval mode, F.batch_norm like the
+reference's fallback, batchnorm.py:40-43).  Only DeepLab-style models use this class (modeling/deeplab.py:16-19)."""
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -42,6 +43,14 @@ class _SynchronizedBatchNorm(_BatchNorm):
 
     def forward(self, input):
         self._check_input_dim(input)
+        if input.dim() == 4 and input.is_cuda and self.track_running_stats and self.momentum is not None:
+            from snws import ops
+            if self.training and self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            # the reference clamps only on its synchronised path; its fallback is F.batch_norm (var + eps)
+            clamp = self._synced()
+            return ops.BatchNormFn.apply(input, self.weight, self.bias, self.running_mean, self.running_var,
+                                         self.momentum, self.eps, self.training, False, True, self.process_group, clamp)
         if not self._synced():
             return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, self.training,
                                 self.momentum, self.eps)

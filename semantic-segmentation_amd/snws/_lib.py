@@ -58,6 +58,10 @@ _SIGNATURES = {
     "snws_resample_fwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_resample_bwd": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, P]),
+    "snws_bn_pack": (c_int, [P, c_int, c_int64, c_int, P, P]),
+    "snws_bn_coeff": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, c_float, c_float, c_int, c_int, P]),
+    "snws_bn_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
+    "snws_bn_bwd_coeff": (c_int, [P, P, P, c_int, c_int, c_float, c_int, P]),
     "snws_adamw_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
     "snws_comm_unique_id": (c_int, [P]),
     "snws_comm_init": (c_int, [P, c_int, c_int, P]),

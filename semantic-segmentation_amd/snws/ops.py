@@ -410,6 +410,96 @@ def sn_backward(dy, s, want_dx_sum=False):
     return dx, dgamma, dbeta, dmw, dvw
 
 
+# ------------------------------------------------------------------------------------------------ BatchNorm
+def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, sync=False, group=None,
+               clamp_eps=False):
+    """nn.BatchNorm2d (optionally + ReLU) of the logical (N,C,H,W) tensor x on the SwitchNorm streaming kernels.
+    sync: all-reduce the packed moments over the process group (SynchronizedBatchNorm2d semantics).  Returns
+    (y, saved)."""
+    require_gpu(x, "BatchNorm2d")
+    N, C, H, W = x.shape
+    HW = H * W
+    dt, dev, lib, st = dtype_code(x), x.device, L.lib(), _stream()
+    xs, ldx = as_nhwc(x)
+    ctx = torch.empty(lib.snws_sn_ctx_floats(N, C), dtype=torch.float32, device=dev)
+    use_batch = training or running_mean is None
+    synced = bool(sync and use_batch and dp_collectives(group))
+    world = sync_world(group) if synced else 1
+    pack = None
+    if use_batch:
+        T = lib.snws_sn_stats_tiles(N, HW, C)
+        part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
+        shift = torch.empty((N, C), dtype=torch.float32, device=dev)
+        _launch("sn_stats", float(x.element_size()) * N * HW * C, "snws_sn_stats", _ptr(xs), dt, N, HW, C, ldx,
+                _ptr(part), _ptr(shift), st)
+        L.call("snws_sn_finalize", _ptr(part), T, _ptr(shift), 1, N, HW, C, _ptr(ctx), st)
+        pack = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
+        L.call("snws_bn_pack", _ptr(ctx), N, HW, C, _ptr(pack), st)
+        if synced:
+            _allreduce_sum(pack, group)
+    g32 = None if gamma is None else _f32c(gamma).view(-1)
+    b32 = torch.zeros(C, dtype=torch.float32, device=dev) if beta is None else _f32c(beta).view(-1)
+    for buf in (running_mean, running_var):
+        if buf is not None and (buf.dtype != torch.float32 or not buf.is_contiguous()):
+            raise TypeError("BatchNorm2d running buffers must be contiguous float32")
+    L.call("snws_bn_coeff", _ptr(ctx), _ptr(pack), _ptr(g32), _ptr(running_mean), _ptr(running_var), N, HW, C, float(eps),
+           float(momentum), int(use_batch), int(bool(clamp_eps)), st)
+    y = new_nhwc(N, C, H, W, x.dtype, dev)
+    _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), C, None, 0, dt,
+            _ptr(ctx), _ptr(b32), N, HW, C, int(relu), st)
+    saved = dict(xs=xs, ldx=ldx, ctx=ctx, beta=b32, gamma=g32 if g32 is not None else torch.ones(C, dtype=torch.float32, device=dev),
+                 relu=bool(relu), shape=(N, C, H, W), batch=use_batch, synced=synced, group=group,
+                 count=float(N * world * HW))
+    return y, saved
+
+
+def bn_backward(dy, s):
+    """Returns (dx, dgamma (C), dbeta (C)) of bn_forward."""
+    N, C, H, W = s["shape"]
+    HW = H * W
+    lib, st = L.lib(), _stream()
+    dys, lddy = as_nhwc(dy)
+    if dys.dtype != s["xs"].dtype:
+        dys, lddy = as_nhwc(dy.to(s["xs"].dtype))
+    dt, dev = dtype_code(dys), dys.device
+    T = lib.snws_sn_stats_tiles(N, HW, C)
+    part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
+    _launch("sn_bwd_reduce", 2.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_reduce", _ptr(dys), lddy, _ptr(s["xs"]),
+            s["ldx"], None, 0, dt, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(s["beta"]), N, HW, C, int(s["relu"]), _ptr(part), st)
+    packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    L.call("snws_bn_bwd_pack", _ptr(part), T, N, C, _ptr(packb), _ptr(dgamma), _ptr(dbeta), st)
+    if s["synced"]:
+        _allreduce_sum(packb, s["group"])
+    ctxb = torch.empty(lib.snws_sn_ctxb_floats(N, C), dtype=torch.float32, device=dev)
+    L.call("snws_bn_bwd_coeff", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), N, C, float(s["count"]), int(s["batch"]), st)
+    dx = new_nhwc(N, C, H, W, dys.dtype, dev)
+    _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]),
+            s["ldx"], None, 0, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C, int(s["relu"]), st)
+    return dx, dgamma, dbeta
+
+
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d.forward (+ optional ReLU) as one differentiable op on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, sync, group, clamp_eps):
+        y, saved = bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, sync, group,
+                              clamp_eps)
+        ctx.s = saved
+        ctx.has = (gamma is not None, beta is not None)
+        ctx.shapes = (None if gamma is None else gamma.shape, None if beta is None else beta.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dg, db = bn_backward(dy, ctx.s)
+        ctx.s = None
+        return (dx, dg.view(ctx.shapes[0]) if ctx.has[0] else None, db.view(ctx.shapes[1]) if ctx.has[1] else None,
+                None, None, None, None, None, None, None, None, None)
+
+
 # ------------------------------------------------------------------------------------------------ autograd
 class Conv2dwsFn(torch.autograd.Function):
     """Conv2dws.forward of modeling/weightstd.py:12-18 as one differentiable op."""

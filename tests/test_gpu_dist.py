@@ -72,6 +72,25 @@ def _worker(rank, world, port, q):
     full_pred = np.argmax(g["logits"], axis=1)
     errs["cm_equal"] = bool(np.array_equal(ev.confusion_matrix,
                                            O.confusion_matrix(lab.numpy(), full_pred, 10).astype(np.float64)))
+    # SynchronizedBatchNorm2d on the HIP kernels: each rank normalises its image with the moments of both
+    from modeling.sync_batchnorm import SynchronizedBatchNorm2d
+    torch.manual_seed(21)
+    xb = torch.randn(2, 6, 9, 11) * 1.3 + 0.2
+    dyb = torch.randn(2, 6, 9, 11)
+    refbn = torch.nn.BatchNorm2d(6).double()
+    xr = xb.double().requires_grad_(True)
+    refbn(xr).backward(dyb.double())
+    sbn = SynchronizedBatchNorm2d(6).to(dev)
+    xs_ = xb[rank:rank + 1].to(dev).requires_grad_(True)
+    ys_ = sbn(xs_)
+    ys_.backward(dyb[rank:rank + 1].to(dev))
+    gsum = sbn.weight.grad.detach().cpu().clone()
+    dist.all_reduce(gsum)
+    errs["syncbn"] = max(
+        float((xs_.grad.cpu().double() - xr.grad[rank:rank + 1]).abs().max() / xr.grad.abs().max()),
+        float((gsum.double() - refbn.weight.grad).abs().max() / refbn.weight.grad.abs().max()),
+        float((sbn.running_var.cpu().double() - refbn.running_var).abs().max()),
+        float((sbn.running_mean.cpu().double() - refbn.running_mean).abs().max()))
     # fused loss head under data parallelism: same global normalisation as the unfused loss
     model.zero_grad(set_to_none=True)
     model.raw_logits = True
@@ -110,7 +129,7 @@ def test_two_rank_step_equals_reference_full_batch():
         print(rank, errs, nb)
         assert nb >= 2
         assert errs["logits"] < 1e-3 and errs["loss"] < 1e-3 and errs["grads"] < 3e-3 and errs["buffers"] < 1e-3
-        assert errs["cm_equal"] and errs["disk_equal"] and errs["fused_loss"] < 1e-5
+        assert errs["cm_equal"] and errs["disk_equal"] and errs["fused_loss"] < 1e-5 and errs["syncbn"] < 1e-4
 
 
 def test_rccl_path_with_one_rank_group():

@@ -989,3 +989,44 @@ def test_trainer_flat_optimizer_matches_torch_optimizer(tmp_path):
     assert abs(l1 - l2) <= 1e-5 * abs(l1)
     for (n, a), (_, b) in zip(model.named_parameters(), fresh.named_parameters()):
         assert relerr(b, a) < 1e-5, n
+
+
+@pytest.mark.parametrize("shape,dtype,relu,tol", [((3, 8, 9, 7), torch.float32, False, 1e-4), ((2, 20, 16, 16), torch.float32, True, 1e-4),
+                                                  ((2, 64, 32, 32), torch.bfloat16, True, 2e-2), ((1, 5, 6, 6), torch.float32, True, 1e-4)])
+def test_hip_batchnorm_vs_torch(shape, dtype, relu, tol):
+    """blocks.HipBatchNorm2d (+ fused ReLU) == nn.BatchNorm2d (+ ReLU): output, input / gamma / beta gradients, running
+    buffers after two training calls, num_batches_tracked, and the eval-mode output."""
+    from modeling.blocks import HipBatchNorm2d
+    torch.manual_seed(9)
+    N, C, H, W = shape
+    ref = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(C) + 0.5)
+        ref.bias.copy_(torch.randn(C) * 0.3)
+    m = HipBatchNorm2d(C, fuse_relu=relu).to(DEV)
+    m.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    x = (torch.randn(shape) * 1.7 + 0.4).to(dtype)
+    dy = torch.randn(shape).to(dtype)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(dy.double())
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = m(xg)
+    y.backward(dy.to(DEV))
+    assert y.dtype == dtype
+    assert relerr(y.float(), yr) < tol and relerr(xg.grad.float(), xr.grad) < tol
+    assert relerr(m.weight.grad, ref.weight.grad) < tol and relerr(m.bias.grad, ref.bias.grad) < tol
+    with torch.no_grad():
+        ref(xr.detach() * 1.5 - 0.2)
+        m(xg.detach() * 1.5 - 0.2)
+    assert relerr(m.running_mean, ref.running_mean) < max(tol, 1e-3) and relerr(m.running_var, ref.running_var) < max(tol, 1e-3)
+    assert int(m.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    ref.eval(); m.eval()
+    with torch.no_grad():
+        ye = ref(xr.detach())
+        ye = torch.relu(ye) if relu else ye
+        assert relerr(m(xg.detach()).float(), ye) < tol
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, C, 4, 4))
