@@ -40,6 +40,41 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Gradient sinks.  An optimizer that keeps every gradient in one flat buffer (snws.optim.FlatAdamW) registers, per
+# parameter, where that parameter's gradient lives.  A backward kernel then writes its result straight into the
+# flat buffer: grad_out() hands out a fresh view of the slot (zero-filled by the optimizer's zero_grad) once per
+# step, autograd adopts the returned view as .grad without launching a copy or an add, and a parameter used a second
+# time in the same step gets an ordinary tensor that autograd accumulates as usual.
+# parameter data_ptr -> (flat gradient, offset, numel, [handed out this step], weakref to the owning optimizer)
+GRAD_SINKS = {}
+
+
+def grad_key(param):
+    return None if param is None else param.data_ptr()
+
+
+def grad_out(key, shape, device, zero=False):
+    """Where a backward kernel should write d(loss)/d(parameter `key` = grad_key(param)): the parameter's slot in
+    the flat gradient buffer when one is registered and still unused in this step, else a new float32 tensor of
+    `shape` (zero-filled on request; a slot always is)."""
+    sink = GRAD_SINKS.get(key) if key is not None else None
+    if sink is not None and sink[4]() is None:      # its optimizer is gone: the address may belong to anyone now
+        del GRAD_SINKS[key]
+        sink = None
+    if sink is not None and not sink[3][0] and sink[2] == _numel(shape):
+        sink[3][0] = True
+        flat, off, n = sink[:3]
+        return flat[off:off + n].view(shape)
+    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=device)
+
+
+def _numel(shape):
+    n = 1
+    for v in shape:
+        n *= int(v)
+    return n
+
+
 PROFILE_ONLY = None     # optional tuple of tag prefixes: only those launches are bracketed (events cost host time)
 
 
@@ -194,8 +229,9 @@ def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
     return y, stat, saved
 
 
-def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db):
-    """Returns (dx or None, dw (O,I/g,kh,kw) f32 or None, dbias f32 or None)."""
+def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=None):
+    """Returns (dx or None, dw (O,I/g,kh,kw) f32 or None, dbias f32 or None).  bias_key: grad_key(bias), which routes
+    the bias gradient to its slot in a flat gradient buffer (the weight's is found through `weight`)."""
     cfg = prep.cfg
     xs, ldx, (N, C, H, W), used_mfma = saved
     dys, lddy = as_nhwc(dy)
@@ -223,7 +259,7 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db):
     if need_dw or need_db:
         done = False
         if need_db:
-            db = torch.zeros(cfg.O, dtype=torch.float32, device=dev)
+            db = grad_out(bias_key, (cfg.O,), dev, zero=True)
         if used_mfma and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
             g = torch.zeros((cfg.O, cfg.kh, cfg.kw, c_run), dtype=torch.float32, device=dev)
             d = cfg.desc(N, H, W, c_run, ldx, lddy)
@@ -244,7 +280,7 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db):
         elif need_dw:
             w32 = weight.detach()
             w32 = (w32 if w32.dtype == torch.float32 else w32.float()).contiguous()
-            dw = torch.empty((cfg.O, cfg.Ig, cfg.kh, cfg.kw), dtype=torch.float32, device=dev)
+            dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), dev)
             L.call("snws_ws_bwd", _ptr(w32), _ptr(g), ldg, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
     return dx, dw, db
 
@@ -368,7 +404,7 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     return y, saved
 
 
-def sn_backward(dy, s, want_dx_sum=False):
+def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None):
     """Returns (dx, dgamma (C), dbeta (C), dmean_weight, dvar_weight[, dx_sum (C)]).  dx_sum is the closed-form
     per-channel sum of dx, i.e. the gradient of a bias added just before the normalisation."""
     N, C, H, W = s["shape"]
@@ -389,16 +425,16 @@ def sn_backward(dy, s, want_dx_sum=False):
             int(s["relu"]), _ptr(part), st)
     ctxb = torch.empty(lib.snws_sn_ctxb_floats(N, C), dtype=torch.float32, device=dev)
     packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    dgamma = grad_out(grad_key(s["gamma"]), (C,), dev)
+    dbeta = grad_out(grad_key(s["beta"]), (C,), dev)
     L.call("snws_sn_bwd_mix_a", _ptr(part), T, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(ctxb), _ptr(packb), _ptr(dgamma),
            _ptr(dbeta), N, C, st)
     if s["synced"]:
         _allreduce_sum(packb, s["group"])
     K = s["mw"].numel()
-    dmw = torch.empty(K, dtype=torch.float32, device=dev)
-    dvw = torch.empty(K, dtype=torch.float32, device=dev)
-    dxsum = torch.empty(C, dtype=torch.float32, device=dev) if want_dx_sum else None
+    dmw = grad_out(grad_key(s["mw"]), (K,), dev)
+    dvw = grad_out(grad_key(s["vw"]), (K,), dev)
+    dxsum = grad_out(dx_sum_key, (C,), dev) if want_dx_sum else None
     L.call("snws_sn_bwd_mix_b", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), _ptr(s["mw"]), _ptr(s["vw"]), None, None,
            _ptr(dmw), _ptr(dvw), _ptr(dxsum), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), st)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
@@ -467,8 +503,8 @@ def bn_backward(dy, s):
     _launch("sn_bwd_reduce", 2.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_reduce", _ptr(dys), lddy, _ptr(s["xs"]),
             s["ldx"], None, 0, dt, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(s["beta"]), N, HW, C, int(s["relu"]), _ptr(part), st)
     packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    dgamma = grad_out(grad_key(s["gamma"]), (C,), dev)
+    dbeta = grad_out(grad_key(s["beta"]), (C,), dev)
     L.call("snws_bn_bwd_pack", _ptr(part), T, N, C, _ptr(packb), _ptr(dgamma), _ptr(dbeta), st)
     if s["synced"]:
         _allreduce_sum(packb, s["group"])
@@ -507,7 +543,7 @@ class Conv2dwsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, prep, force_direct):
         y, _, saved = conv_forward(x, prep, bias, want_stats=False, force_direct=force_direct)
-        ctx.prep, ctx.saved, ctx.has_bias = prep, saved, bias is not None
+        ctx.prep, ctx.saved, ctx.has_bias, ctx.bias_key = prep, saved, bias is not None, grad_key(bias)
         ctx.save_for_backward(weight)
         return y
 
@@ -515,7 +551,7 @@ class Conv2dwsFn(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb)
+        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key)
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db, None, None
@@ -529,7 +565,7 @@ class PlainConvFn(torch.autograd.Function):
         cfg = ConvCfg(weight.shape, 1, (weight.shape[2] - 1) // 2, 1, 1)
         prep = PreparedWeight(weight, cfg, x.dtype == torch.bfloat16, standardize=False)
         y, _, saved = conv_forward(x, prep, bias)
-        ctx.prep, ctx.saved, ctx.has_bias = prep, saved, bias is not None
+        ctx.prep, ctx.saved, ctx.has_bias, ctx.bias_key = prep, saved, bias is not None, grad_key(bias)
         ctx.save_for_backward(weight)
         return y
 
@@ -537,7 +573,7 @@ class PlainConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb)
+        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key)
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db
@@ -572,6 +608,7 @@ class ConvSnReluFn(torch.autograd.Function):
                                                                        device=x.device)
         y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift, out=out)
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
+        ctx.bias_key = grad_key(bias)
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.save_for_backward(weight)
         return y
@@ -582,7 +619,7 @@ class ConvSnReluFn(torch.autograd.Function):
         dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn)
         ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb)
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key)
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
@@ -603,6 +640,7 @@ class ConvSnAddReluFn(torch.autograd.Function):
                                                                        device=x.device)
         y, sn_saved = sn_forward(conv_out, p, True, stat_part=stat, stat_shift=shift, residual=residual)
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
+        ctx.bias_key = grad_key(bias)
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.res_dtype = residual.dtype
         ctx.save_for_backward(weight)
@@ -618,7 +656,7 @@ class ConvSnAddReluFn(torch.autograd.Function):
             dres = torch.where(y > 0, dy.to(y.dtype), torch.zeros((), dtype=y.dtype, device=y.device)).to(ctx.res_dtype)
         ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb)
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key)
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
@@ -663,7 +701,7 @@ class TapConvFn(torch.autograd.Function):
         if dwre is not None:
             g = dwre.view(cfg.kh, cfg.kw, cfg.O, cfg.Ig).permute(2, 0, 1, 3).contiguous()
             w32 = _f32c(weight)
-            dw = torch.empty((cfg.O, cfg.Ig, cfg.kh, cfg.kw), dtype=torch.float32, device=g.device)
+            dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), g.device)
             L.call("snws_ws_bwd", _ptr(w32), _ptr(g), cfg.Ig, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
             dw = dw.to(weight.dtype)
         ctx.saved = None
@@ -686,13 +724,14 @@ class UpTapSnReluFn(torch.autograd.Function):
                 h, w, c_out, k, ksize, _stream())
         y, sn_saved = sn_forward(conv_out, p, relu, out=out)
         ctx.sn, ctx.meta, ctx.has_bias = sn_saved, (N, h, w, k, ksize, c_out, CZ), bias is not None
+        ctx.bias_key = grad_key(bias)
         ctx.shapes = (gamma.shape, beta.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         N, h, w, k, ksize, c_out, CZ = ctx.meta
-        dconv, dg, dbeta, dmw, dvw, dxsum = sn_backward(dy, ctx.sn, want_dx_sum=True)
+        dconv, dg, dbeta, dmw, dvw, dxsum = sn_backward(dy, ctx.sn, want_dx_sum=True, dx_sum_key=ctx.bias_key)
         ctx.sn = None
         dz = new_nhwc(N, CZ, h, w, dconv.dtype, dconv.device)
         work = float(dconv.element_size()) * N * c_out * (h * w * ksize * ksize + h * k * w * k)

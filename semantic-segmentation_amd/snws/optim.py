@@ -1,12 +1,17 @@
 """AdamW over ONE flat parameter buffer: the reference's torch.optim.AdamW(model.parameters(), lr, weight_decay)
 (train.py:81, stepped at train.py:254) as a single fused HIP launch.
 
-All parameters are re-pointed to views of one float32 buffer and their .grad to views of a second one, so autograd
-accumulates straight into the flat gradient, zero_grad is one memset, a data-parallel all-reduce can run on slices
-of it without flatten/unflatten copies, and the update is one pass over four flat arrays.  state_dict() /
+All parameters are re-pointed to views of one float32 buffer, and every parameter owns a slot in a second one, the
+flat gradient.  The slots are registered as gradient sinks (snws.ops.GRAD_SINKS): the backward kernels write
+d(loss)/d(parameter) straight into the slot and autograd adopts that view as .grad, so no per-parameter add or copy
+is launched; a gradient that arrives any other way (a stock torch op, a second use of the parameter) is added or
+copied into the slot by the post-accumulate hook.  zero_grad is one memset, a data-parallel all-reduce runs on slices
+of the flat gradient without flatten/unflatten copies, and the update is one pass over four flat arrays.  state_dict() /
 load_state_dict() speak torch.optim.AdamW's format, so the 'optimizer' entry of a reference checkpoint
 (train.py:226, 272-277) loads and saves unchanged.  Like torch, a parameter that received no gradient in a step is
 left alone in that step (no weight decay, no moment decay)."""
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -39,7 +44,8 @@ class FlatAdamW:
                 n = p.numel()
                 self.flat_p[o:o + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
-                p.grad = self.flat_g[o:o + n].view(p.shape)
+                p.grad = None
+                ops.GRAD_SINKS[p.data_ptr()] = (self.flat_g, o, n, [False], weakref.ref(self))
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
         self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
                                   amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
@@ -47,17 +53,28 @@ class FlatAdamW:
         self.steps = [0] * len(self.params)          # per-parameter update counts, as torch keeps them
 
     def _make_hook(self, i):
-        def hook(_p):
+        o = self.offsets[i]
+
+        def hook(p):
             self._touched[i] = True
+            if p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:     # not produced in place: move it into the slot
+                with torch.no_grad():
+                    slot = self.flat_g[o:o + p.numel()].view(p.shape)
+                    slot.copy_(p.grad)
+                    p.grad = slot
         return hook
 
     # -------------------------------------------------------------------------------------------- torch.optim surface
-    def zero_grad(self, set_to_none=False):
-        """Always keeps the flat gradient views (set_to_none is accepted for API compatibility and ignored)."""
+    def zero_grad(self, set_to_none=True):
+        """Clears the flat gradient (one memset) and re-arms every parameter's gradient sink.  .grad is always reset
+        to None so that autograd adopts the view a backward kernel wrote into (set_to_none is accepted for API
+        compatibility)."""
         self.flat_g.zero_()
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
-                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        for p in self.params:
+            p.grad = None
+            sink = ops.GRAD_SINKS.get(p.data_ptr())
+            if sink is not None:
+                sink[3][0] = False
         self._touched = [False] * len(self.params)
 
     @torch.no_grad()

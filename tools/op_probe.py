@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Lists the stock torch ops (name, input shapes, count) that one training step of the bench model still launches.
+    python tools/op_probe.py [filter substring]"""
+import collections
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "semantic-segmentation_amd"))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from modeling.UNet3p_SNws import UNet3p_SNws
+from snws import harness
+
+flt = sys.argv[1] if len(sys.argv) > 1 else "add"
+dev = torch.device("cuda", 0)
+model = UNet3p_SNws(14, 64, 10, 1, 1).to(dev).to(memory_format=torch.channels_last)
+model.compute_dtype = torch.bfloat16
+tr = harness.Trainer(model, total_iters=100)
+img, lab = harness.synthetic_batch(4, 14, 256, 10, dev)
+for _ in range(2):
+    tr.step(img, lab)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU], record_shapes=True, with_stack=False) as prof:
+    tr.step(img, lab)
+    torch.cuda.synchronize()
+cnt = collections.Counter()
+for e in prof.events():
+    if flt in e.name:
+        cnt[(e.name, str(e.input_shapes))] += 1
+for k, v in sorted(cnt.items(), key=lambda kv: -kv[1]):
+    print(v, k)
