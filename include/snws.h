@@ -103,6 +103,26 @@ int snws_conv_mfma_tiles(int H, int W);
 int snws_conv_mfma_fwd(const snws_conv_desc* d, const void* x, const void* pack_fwd, const float* bias, void* y,
                        float* stat_part, void* stream);
 int snws_conv_mfma_dgrad(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx, void* stream);
+/* dgrad whose epilogue also runs pass 1 of the SwitchNorm backward (what snws_sn_bwd_reduce computes) for the
+ * SwitchNorm(+ReLU) layers that produced this convolution's input: the gradient this launch writes, dx, IS their
+ * incoming gradient when the convolution is their only consumer (autograd of modeling/snorm.py:41-81 chained to
+ * F.conv2d, modeling/weightstd.py:18), so the tile that is being stored is reduced on the way out instead of being
+ * read back.  A segment = one such layer occupying input channels [c_begin, c_begin + c_count) of the convolution
+ * (several when the input is a channel concatenation): x / ldx its bf16 input, ctx its snws_sn_ctx_floats(N, c_count)
+ * forward coefficients, beta its bias, relu whether a ReLU follows it; part receives [N][T][c_count][2] partial
+ * sums, T = snws_conv_mfma_tiles(H, W), in the layout snws_sn_bwd_mix_a / snws_bn_bwd_pack take.
+ * c_begin must be a multiple of 64, c_count of 8, segments must not overlap, C_in <= 1024. */
+typedef struct snws_sn_bwd_seg {
+  int c_begin, c_count;
+  const void* x;
+  int64_t ldx;
+  const float* ctx;
+  const float* beta;
+  float* part;
+  int relu;
+} snws_sn_bwd_seg;
+int snws_conv_mfma_dgrad_sn(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx,
+                            const snws_sn_bwd_seg* segs, int n_segs, void* stream);
 int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
                          void* stream);
 

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "pack.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -46,6 +47,19 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// One 64-output-channel tile of a dgrad launch whose output is also the incoming gradient of a SwitchNorm(+ReLU)
+// layer: the epilogue then produces that layer's backward partial sums (what sn_bwd_reduce would compute).
+struct SnBwdTile {
+  const bf16_t* x;       // the layer's input, already offset to this tile's first channel
+  const float* mean;     // per (image, channel) coefficients of the layer, offset likewise; image stride = cseg
+  const float* rstd;
+  const float* scale;
+  const float* beta;     // per channel, offset likewise
+  float* part;           // [N][T][cseg][2], offset to this tile's first channel; nullptr = no layer on this tile
+  int ldx, cseg, cvalid, relu;   // cvalid = channels of the layer inside this tile
+};
+constexpr int MAX_BWR_TILES = 16;
+
 struct FwdArgs {
   const bf16_t* x;
   const bf16_t* pack;
@@ -55,6 +69,8 @@ struct FwdArgs {
   int N, H, W, Cout;
   int64_t ldx, ldy;
   int tilesX, tilesY, coTiles, nchunks;
+  int nbwr;                       // > 0: bwr[0 .. coTiles) is valid
+  SnBwdTile bwr[MAX_BWR_TILES];
 };
 
 constexpr int FWD_TH = 16, FWD_TW = 32;
@@ -294,14 +310,44 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
   //      lane holds pixel r of its 32-pixel row and out channels (reg&3) + 8*(reg>>2) + 4*h.
   const int co0 = ct * 64;
   unsigned char* out_lds = smem;
+  // store phase mapping: 8 lanes x 16 B = one pixel's 64 channels; a pass covers one 32-pixel tile row, so a thread
+  // keeps its column (tid >> 3) and channel group (tid & 7) and walks down the 16 rows with a constant stride
+  const int j8 = tid & 7, q0 = tid >> 3;
+  const int gxs = x0 + q0;
+  const int rows = a.H - y0 < FWD_TH ? a.H - y0 : FWD_TH;      // block-uniform
+  // A dgrad launch that also reduces for a SwitchNorm layer needs that layer's input at the pixels this thread will
+  // store: all 16 loads are issued here, so their latency overlaps the accumulator write-out and the barrier.
+  const bool bw = a.nbwr > 0 && a.bwr[ct].part != nullptr;     // block-uniform
+  const bool bwc = bw && j8 * 8 < a.bwr[ct].cvalid && gxs < a.W;
+  uint4 xin[16];
+  if (bw) {
+    const SnBwdTile& g = a.bwr[ct];
+    if (bwc) {
+      const bf16_t* bx = g.x + (((int64_t)n * a.H + y0) * a.W + gxs) * g.ldx + j8 * 8;
+      const int64_t bstep = (int64_t)a.W * g.ldx;
+      if (rows == FWD_TH) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xin[i] = *reinterpret_cast<const uint4*>(bx + i * bstep);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < rows) xin[i] = *reinterpret_cast<const uint4*>(bx + i * bstep);
+      }
+    }
+  }
+  // (two inlined copies: a reducing dgrad launch has no bias, and a bias load here would make the compiler wait for
+  //  every load in flight, the xin prefetch included)
+  auto write_acc = [&](auto with_bias) {
+  constexpr bool BIAS = decltype(with_bias)::value;
+  const float* bias = a.bias;
   if constexpr (M16) {   // lane holds column r of a 16-pixel half row and out channels c4*16 + 4*h + (0..3)
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
       const int cl = c4 * 16 + 4 * h;
       float b4[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) {
+      if constexpr (BIAS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b4[e] = (co0 + cl + e < a.Cout) ? a.bias[co0 + cl + e] : 0.f;
+        for (int e = 0; e < 4; ++e) b4[e] = (co0 + cl + e < a.Cout) ? bias[co0 + cl + e] : 0.f;
       }
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
@@ -319,9 +365,9 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
     for (int g = 0; g < 4; ++g) {
       const int cl = c2 * 32 + 8 * g + 4 * h;  // first of 4 consecutive channels
       float b4[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) {
+      if constexpr (BIAS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b4[e] = (co0 + cl + e < a.Cout) ? a.bias[co0 + cl + e] : 0.f;
+        for (int e = 0; e < 4; ++e) b4[e] = (co0 + cl + e < a.Cout) ? bias[co0 + cl + e] : 0.f;
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -334,10 +380,13 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
     }
   }
   }
+  };
+  if (bw || !a.bias) write_acc(std::false_type{}); else write_acc(std::true_type{});
   __syncthreads();
 
-  // ---- coalesced stores (8 lanes x 16 B = one pixel's 64 channels) + per-channel partial moments
-  const int j8 = tid & 7, q0 = tid >> 3;
+  // ---- coalesced stores (8 lanes x 16 B = one pixel's 64 channels) + per-channel partial sums: either the moments
+  //      of the output (forward: SwitchNorm statistics) or, for a dgrad launch, sum(g) and sum(g * xhat) of the
+  //      SwitchNorm layer this gradient belongs to (g = dy masked by the layer's ReLU, recomputed from its input)
   const int cbase = co0 + j8 * 8;
   const bool cok = cbase < a.Cout;
   float sh[8], S[8], Q[8];
@@ -346,26 +395,85 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
     sh[e] = (a.stat && a.bias && cok) ? a.bias[cbase + e] : 0.f;
     S[e] = Q[e] = 0.f;
   }
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int q = q0 + 32 * i;
-    const int gy = y0 + (q >> 5), gx = x0 + (q & 31);
-    if (cok && gy < a.H && gx < a.W) {
-      const uint4 v = *reinterpret_cast<const uint4*>(out_lds + q * OUT_STRIDE + j8 * 16);
-      *reinterpret_cast<uint4*>(a.y + (((int64_t)n * a.H + gy) * a.W + gx) * a.ldy + cbase) = v;
-      if (a.stat) {
-        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+  const bool lane_ok = cok && gxs < a.W;
+  const unsigned char* lp = out_lds + q0 * OUT_STRIDE + j8 * 16;
+  bf16_t* yp = a.y + (((int64_t)n * a.H + y0) * a.W + gxs) * a.ldy + cbase;
+  const int64_t ystep = (int64_t)a.W * a.ldy;
+  // (every loop below exists twice: straight-line for a full 16-row tile, row-checked for the bottom image border)
+  if (bw) {   // block-uniform
+    // (the output tile itself is stored at the very end: loads and stores share one in-flight counter and may
+    // complete out of order with respect to each other, so a wait for xin[i] issued after a store would also drain
+    // the stores - and so would the barrier of the cross-wave reduction below)
+    const SnBwdTile& g = a.bwr[ct];
+    float mu[8], sc[8], be[8], rs[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float f0 = __uint_as_float(u[e] << 16) - sh[2 * e];
-          const float f1 = __uint_as_float(u[e] & 0xffff0000u) - sh[2 * e + 1];
-          S[2 * e] += f0; Q[2 * e] += f0 * f0;
-          S[2 * e + 1] += f1; Q[2 * e + 1] += f1 * f1;
-        }
+    for (int e = 0; e < 8; ++e) {
+      mu[e] = rs[e] = sc[e] = 0.f;
+      be[e] = g.relu ? 0.f : 1.f;
+    }
+    if (bwc) {
+      // the layer's per-(image, channel) coefficients for this thread's 8 channels (32-byte aligned groups)
+      const int64_t ci = (int64_t)n * g.cseg + j8 * 8;
+      const float4 m0 = *reinterpret_cast<const float4*>(g.mean + ci), m1 = *reinterpret_cast<const float4*>(g.mean + ci + 4);
+      const float4 r0 = *reinterpret_cast<const float4*>(g.rstd + ci), r1 = *reinterpret_cast<const float4*>(g.rstd + ci + 4);
+      mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
+      rs[0] = r0.x; rs[1] = r0.y; rs[2] = r0.z; rs[3] = r0.w; rs[4] = r1.x; rs[5] = r1.y; rs[6] = r1.z; rs[7] = r1.w;
+      if (g.relu) {   // no ReLU after the layer: scale 0, bias 1 make the mask expression true for every finite input
+        const float4 s0 = *reinterpret_cast<const float4*>(g.scale + ci), s1 = *reinterpret_cast<const float4*>(g.scale + ci + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(g.beta + j8 * 8), b1 = *reinterpret_cast<const float4*>(g.beta + j8 * 8 + 4);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w;
       }
     }
+    auto reduce_row = [&](int i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(lp + i * 32 * OUT_STRIDE);
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+      const unsigned w[4] = {xin[i].x, xin[i].y, xin[i].z, xin[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g0 = __uint_as_float(u[e] << 16), g1 = __uint_as_float(u[e] & 0xffff0000u);
+        const float e0 = __uint_as_float(w[e] << 16) - mu[2 * e];
+        const float e1 = __uint_as_float(w[e] & 0xffff0000u) - mu[2 * e + 1];
+        g0 = fmaf(e0, sc[2 * e], be[2 * e]) > 0.f ? g0 : 0.f;
+        g1 = fmaf(e1, sc[2 * e + 1], be[2 * e + 1]) > 0.f ? g1 : 0.f;
+        S[2 * e] += g0; Q[2 * e] = fmaf(g0, e0, Q[2 * e]);
+        S[2 * e + 1] += g1; Q[2 * e + 1] = fmaf(g1, e1, Q[2 * e + 1]);
+      }
+    };
+    if (lane_ok && bwc) {
+      if (rows == FWD_TH) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) reduce_row(i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < rows) reduce_row(i);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Q[e] *= rs[e];     // sum(g * (x - mean)) * rstd = sum(g * xhat)
+  } else if (a.stat && lane_ok) {
+    auto stat_row = [&](int i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(lp + i * 32 * OUT_STRIDE);
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f0 = __uint_as_float(u[e] << 16) - sh[2 * e];
+        const float f1 = __uint_as_float(u[e] & 0xffff0000u) - sh[2 * e + 1];
+        S[2 * e] += f0; Q[2 * e] += f0 * f0;
+        S[2 * e + 1] += f1; Q[2 * e + 1] += f1 * f1;
+      }
+    };
+    if (rows == FWD_TH) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) stat_row(i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < rows) stat_row(i);
+    }
   }
-  if (a.stat) {
+  if (a.stat || bw) {
     float* st_lds = reinterpret_cast<float*>(smem + OUT_BYTES);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -383,18 +491,35 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
       }
     }
     __syncthreads();
-    if (tid < 64 && co0 + tid < a.Cout) {
+    const int64_t tile = (int64_t)ty * a.tilesX + tx;
+    const int64_t T = (int64_t)a.tilesX * a.tilesY;
+    float* o = nullptr;
+    if (bw) {
+      if (tid < a.bwr[ct].cvalid) o = a.bwr[ct].part + (((int64_t)n * T + tile) * a.bwr[ct].cseg + tid) * 2;
+    } else if (tid < 64 && co0 + tid < a.Cout) {
+      o = a.stat + (((int64_t)n * T + tile) * a.Cout + co0 + tid) * 2;
+    }
+    if (o) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         s += st_lds[(w * 64 + tid) * 2];
         q += st_lds[(w * 64 + tid) * 2 + 1];
       }
-      const int64_t tile = (int64_t)ty * a.tilesX + tx;
-      const int64_t T = (int64_t)a.tilesX * a.tilesY;
-      float* o = a.stat + (((int64_t)n * T + tile) * a.Cout + co0 + tid) * 2;
       o[0] = s;
       o[1] = q;
+    }
+  }
+  // ---- the output tile, last: nothing in this workgroup waits for these stores
+  if (lane_ok) {
+    if (rows == FWD_TH) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        *reinterpret_cast<uint4*>(yp + i * ystep) = *reinterpret_cast<const uint4*>(lp + i * 32 * OUT_STRIDE);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < rows) *reinterpret_cast<uint4*>(yp + i * ystep) = *reinterpret_cast<const uint4*>(lp + i * 32 * OUT_STRIDE);
     }
   }
 }
@@ -848,7 +973,8 @@ int launch_fwd(const FwdArgs& a, unsigned grid, hipStream_t st) {
 
 // runs y(C_out_run channels) = conv(x(C_in_run channels), pack)
 int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_run, int taps, const void* x, int64_t ldx,
-                 const void* pack, const float* bias, void* y, int64_t ldy, float* stat, hipStream_t st) {
+                 const void* pack, const float* bias, void* y, int64_t ldy, float* stat, hipStream_t st,
+                 const snws_sn_bwd_seg* segs = nullptr, int n_segs = 0) {
   SNWS_CHECK_ARG(x && pack && y, "%s: NULL pointer", fn);
   SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)pack & 15) == 0,
                  "%s: pointers must be 16-byte aligned", fn);
@@ -857,6 +983,37 @@ int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_ru
   a.x = (const bf16_t*)x; a.pack = (const bf16_t*)pack; a.bias = bias; a.y = (bf16_t*)y; a.stat = stat;
   a.N = N; a.H = H; a.W = W; a.Cout = c_out_run; a.ldx = ldx; a.ldy = ldy;
   a.tilesX = cdiv(W, FWD_TW); a.tilesY = cdiv(H, FWD_TH); a.coTiles = g.c_out_p / 64; a.nchunks = g.nchunks;
+  a.nbwr = 0;
+  if (n_segs > 0) {
+    if (a.coTiles > MAX_BWR_TILES) SNWS_UNSUPPORTED("%s: more than %d output-channel tiles", fn, MAX_BWR_TILES * 64);
+    for (int t = 0; t < MAX_BWR_TILES; ++t) a.bwr[t] = SnBwdTile{};
+    for (int i = 0; i < n_segs; ++i) {
+      const snws_sn_bwd_seg& sg = segs[i];
+      SNWS_CHECK_ARG(sg.x && sg.ctx && sg.beta && sg.part, "%s: NULL pointer in segment %d", fn, i);
+      SNWS_CHECK_ARG(sg.c_begin >= 0 && sg.c_count > 0 && sg.c_begin % 64 == 0 && sg.c_count % 8 == 0 &&
+                         sg.c_begin + sg.c_count <= c_out_run,
+                     "%s: segment %d covers channels [%d, %d): begin must be a multiple of 64, count of 8, inside %d",
+                     fn, i, sg.c_begin, sg.c_begin + sg.c_count, c_out_run);
+      SNWS_CHECK_ARG(((uintptr_t)sg.x & 15) == 0 && sg.ldx % 8 == 0 && sg.ldx >= sg.c_count,
+                     "%s: segment %d input must be 16-byte aligned with a pixel stride that is a multiple of 8", fn, i);
+      const int64_t nc = (int64_t)N * sg.c_count;     // ctx layout: [mean_in][var_in][mean][rstd][scale], N*C each
+      for (int c = 0; c < sg.c_count; c += 64) {
+        SnBwdTile& tl = a.bwr[(sg.c_begin + c) / 64];
+        SNWS_CHECK_ARG(tl.part == nullptr, "%s: segments overlap at channel %d", fn, sg.c_begin + c);
+        tl.x = (const bf16_t*)sg.x + c;
+        tl.mean = sg.ctx + 2 * nc + c;
+        tl.rstd = sg.ctx + 3 * nc + c;
+        tl.scale = sg.ctx + 4 * nc + c;
+        tl.beta = sg.beta + c;
+        tl.part = sg.part + 2 * c;
+        tl.ldx = (int)sg.ldx;
+        tl.cseg = sg.c_count;
+        tl.cvalid = sg.c_count - c < 64 ? sg.c_count - c : 64;
+        tl.relu = sg.relu;
+      }
+    }
+    a.nbwr = a.coTiles;
+  }
   const int64_t nblk = (int64_t)N * a.tilesX * a.tilesY * a.coTiles;
   SNWS_CHECK_ARG(nblk < (1ll << 31), "%s: grid too large", fn);
   if (g.KC == 32) return taps == 9 ? launch_fwd<32, 9>(a, (unsigned)nblk, st) : launch_fwd<32, 1>(a, (unsigned)nblk, st);
@@ -916,6 +1073,15 @@ extern "C" int snws_conv_mfma_dgrad(const snws_conv_desc* d, const void* dy, con
   if (d->C_out % 16 || d->C_in % 8) SNWS_UNSUPPORTED("snws_conv_mfma_dgrad: C_out %d must be a multiple of 16 and C_in %d of 8", d->C_out, d->C_in);
   return run_fwd_like("snws_conv_mfma_dgrad", d->N, d->H, d->W, d->C_out, d->C_in, d->kh * d->kw, dy, d->ldy, pack_dgrad,
                       nullptr, dx, d->ldx, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int snws_conv_mfma_dgrad_sn(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx,
+                                       const snws_sn_bwd_seg* segs, int n_segs, void* stream) {
+  if (int rc = check_mfma_desc(d, "snws_conv_mfma_dgrad_sn")) return rc;
+  if (d->C_out % 16 || d->C_in % 8) SNWS_UNSUPPORTED("snws_conv_mfma_dgrad_sn: C_out %d must be a multiple of 16 and C_in %d of 8", d->C_out, d->C_in);
+  SNWS_CHECK_ARG(n_segs >= 0 && (n_segs == 0 || segs), "snws_conv_mfma_dgrad_sn: bad segment list");
+  return run_fwd_like("snws_conv_mfma_dgrad_sn", d->N, d->H, d->W, d->C_out, d->C_in, d->kh * d->kw, dy, d->ldy, pack_dgrad,
+                      nullptr, dx, d->ldx, nullptr, (hipStream_t)stream, segs, n_segs);
 }
 
 extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,

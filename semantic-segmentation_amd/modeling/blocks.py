@@ -35,8 +35,9 @@ class ConvSnRelu(nn.Sequential):
             if out is not None:
                 raise NotImplementedError("out= is not available with force_direct")
             return y
-        return ops.ConvSnReluFn.apply(x, conv.weight, conv.bias, norm.weight, norm.bias, norm.mean_weight,
-                                      norm.var_weight, prep, ops.SNParams(norm), True, out)
+        return ops.tag_sn_output(ops.ConvSnReluFn.apply(x, conv.weight, conv.bias, norm.weight, norm.bias,
+                                                        norm.mean_weight, norm.var_weight, prep, ops.SNParams(norm),
+                                                        True, out))
 
 
     # ---- the block applied to nn.Upsample(scale_factor=k, mode='bilinear')(x), without building the up-sampled map
@@ -49,8 +50,9 @@ class ConvSnRelu(nn.Sequential):
 
     def up(self, z, k, out=None):
         conv, norm = self[0], self[1]
-        return ops.UpTapSnReluFn.apply(z, conv.bias, norm.weight, norm.bias, norm.mean_weight, norm.var_weight,
-                                       ops.SNParams(norm), int(k), conv.kernel_size[0], conv.out_channels, True, out)
+        return ops.tag_sn_output(ops.UpTapSnReluFn.apply(z, conv.bias, norm.weight, norm.bias, norm.mean_weight,
+                                                         norm.var_weight, ops.SNParams(norm), int(k),
+                                                         conv.kernel_size[0], conv.out_channels, True, out))
 
     def on_upsampled(self, x, k):
         """== self(nn.Upsample(scale_factor=k, mode='bilinear', align_corners=False)(x))."""
@@ -153,8 +155,9 @@ class Resnet_BasicBlock(nn.Module):
         ops.require_gpu(x, "Resnet_BasicBlock")
         mf = x.dtype == torch.bfloat16
         c1, n1, c2, n2 = self.conv1, self.bn1, self.conv2, self.bn2
-        t = ops.ConvSnReluFn.apply(x, c1.weight, c1.bias, n1.weight, n1.bias, n1.mean_weight, n1.var_weight,
-                                   c1.prepared(mf and not c1.force_direct), ops.SNParams(n1), True, None)
+        t = ops.tag_sn_output(ops.ConvSnReluFn.apply(x, c1.weight, c1.bias, n1.weight, n1.bias, n1.mean_weight,
+                                                     n1.var_weight, c1.prepared(mf and not c1.force_direct),
+                                                     ops.SNParams(n1), True, None))
         if self.downsample is not None:
             # the reference feeds conv2's OUTPUT to downsample (:156); kept, unfused
             y = ops.Conv2dwsFn.apply(t, c2.weight, c2.bias, c2.prepared(mf and not c2.force_direct), c2.force_direct)
@@ -215,5 +218,5 @@ def full_scale_decoder(m, enc, pools=None):
                 parts.append(m.convu_cat.up(zdec[src], 2 ** (src - level), out=out))
         # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
         parts.append(m.conv5_cat.up(z5, 2 ** (5 - level), out=buf[:, 4 * f:5 * f]))
-        dec[level] = m.conv_fusion(ops.AssembleFn.apply(buf, *parts))
+        dec[level] = m.conv_fusion(ops.assemble(buf, parts))
     return dec[1]

@@ -21,6 +21,11 @@ class ConvDesc(Structure):
                 ("ldx", c_int64), ("ldy", c_int64)]
 
 
+class SnBwdSeg(Structure):
+    _fields_ = [("c_begin", c_int), ("c_count", c_int), ("x", c_void_p), ("ldx", c_int64), ("ctx", c_void_p),
+                ("beta", c_void_p), ("part", c_void_p), ("relu", c_int)]
+
+
 P = c_void_p
 _SIGNATURES = {
     "snws_version": (c_int, []),
@@ -38,6 +43,7 @@ _SIGNATURES = {
     "snws_conv_mfma_tiles": (c_int, [c_int, c_int]),
     "snws_conv_mfma_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "snws_conv_mfma_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    "snws_conv_mfma_dgrad_sn": (c_int, [POINTER(ConvDesc), P, P, P, POINTER(SnBwdSeg), c_int, P]),
     "snws_conv_mfma_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "snws_sn_ctx_floats": (c_int64, [c_int, c_int]),
     "snws_sn_ctxb_floats": (c_int64, [c_int, c_int]),

@@ -229,9 +229,77 @@ def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
     return y, stat, saved
 
 
-def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=None):
+# SwitchNorm-backward fusion.  A fused block tags its output with the SwitchNorm state it saved for backward
+# (tag_sn_output / assemble); a convolution that consumes a tagged tensor remembers the tags, and its dgrad launch
+# then also produces pass 1 of those layers' backward (the per-tile sums of snws_sn_bwd_reduce) while it stores the
+# gradient.  The layer uses them only if the gradient it finally receives is that very buffer, unmodified - i.e. the
+# convolution was its only consumer; otherwise it runs its own reduce pass.
+FUSE_SN_BWD = True
+FUSED_SN_BWD_HITS = 0      # layers whose backward reused a consumer's partial sums (diagnostics / tests)
+
+
+def tag_sn_output(y):
+    """Mark y (the output of a fused conv+SwitchNorm block) as 'channels [0, C) come from the SwitchNorm whose
+    backward state is y.grad_fn.sn'."""
+    fn = y.grad_fn
+    s = getattr(fn, "sn", None) if fn is not None else None
+    if isinstance(s, dict) and s.get("y") is None:
+        y._snws_seg = [(0, y.shape[1], s)]
+    return y
+
+
+def input_segments(x):
+    """The SwitchNorm tags of a convolution input, when they qualify for the fused dgrad epilogue: every tagged layer
+    starts at a multiple of 64 channels, spans a multiple of 8, and stores bf16."""
+    segs = getattr(x, "_snws_seg", None) if FUSE_SN_BWD else None
+    if not segs or x.dtype != torch.bfloat16 or x.shape[1] > 1024:
+        return None
+    for c0, c, s in segs:
+        if c0 % 64 or c % 8 or s["xs"].dtype != torch.bfloat16 or s["ldx"] % 8 or s["xs"].data_ptr() % 16:
+            return None
+    return segs
+
+
+def _launch_dgrad(cfg, d, dys, prep, dxp, segs, N, H, W, flops):
+    tag = "conv_mfma_dgrad_k%d_kc%d" % (cfg.kh, 32 if cfg.O % 32 == 0 else 16)
+    if not segs:
+        _launch(tag, flops, "snws_conv_mfma_dgrad", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), _stream())
+        return
+    T = L.lib().snws_conv_mfma_tiles(H, W)
+    arr = (L.SnBwdSeg * len(segs))()
+    parts = []
+    for i, (c0, c, s) in enumerate(segs):
+        part = torch.empty((N, T, c, 2), dtype=torch.float32, device=dxp.device)
+        parts.append(part)
+        arr[i] = L.SnBwdSeg(c0, c, s["xs"].data_ptr(), s["ldx"], s["ctx"].data_ptr(), s["beta"].data_ptr(),
+                            part.data_ptr(), int(s["relu"]))
+    _launch(tag, flops, "snws_conv_mfma_dgrad_sn", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), arr,
+            len(segs), _stream())
+    for (c0, c, s), part in zip(segs, parts):
+        # (partials, tiles, the gradient buffer - kept alive so its address cannot be recycled -, its version, channel)
+        s["fused_bwd"] = (part, T, dxp, dxp._version, c0)
+
+
+def fused_bwd_partials(s, dys, lddy):
+    """The partial sums a consumer's dgrad epilogue left for this SwitchNorm layer, if `dys` is exactly the gradient
+    that launch wrote (same memory, never modified since); else None."""
+    fb = s.pop("fused_bwd", None)
+    if fb is None:
+        return None
+    part, T, dxp, version, c0 = fb
+    if dys.dtype != dxp.dtype or dys.data_ptr() != dxp.data_ptr() + c0 * dxp.element_size() or \
+            lddy != dxp.shape[1] or dys._version != version or dxp._version != version or \
+            tuple(dys.shape[2:]) != tuple(dxp.shape[2:]) or dys.shape[0] != dxp.shape[0] or dys.shape[1] != part.shape[2]:
+        return None
+    global FUSED_SN_BWD_HITS
+    FUSED_SN_BWD_HITS += 1
+    return part, T
+
+
+def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=None, in_segs=None):
     """Returns (dx or None, dw (O,I/g,kh,kw) f32 or None, dbias f32 or None).  bias_key: grad_key(bias), which routes
-    the bias gradient to its slot in a flat gradient buffer (the weight's is found through `weight`)."""
+    the bias gradient to its slot in a flat gradient buffer (the weight's is found through `weight`).  in_segs: the
+    SwitchNorm tags of the convolution's input (input_segments)."""
     cfg = prep.cfg
     xs, ldx, (N, C, H, W), used_mfma = saved
     dys, lddy = as_nhwc(dy)
@@ -246,8 +314,7 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=N
             d = cfg.desc(N, H, W, c_run, c_run, lddy)
             try:
                 flops = 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw
-                _launch("conv_mfma_dgrad_k%d_kc%d" % (cfg.kh, 32 if cfg.O % 32 == 0 else 16), flops,
-                        "snws_conv_mfma_dgrad", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), _stream())
+                _launch_dgrad(cfg, d, dys, prep, dxp, in_segs, N, H, W, flops)
                 dx = dxp[:, :C] if c_run != C else dxp
                 done = True
             except L.SnwsUnsupported:
@@ -418,11 +485,15 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None):
     dev = dys.device
     ym = s["y"]
     yms, ldym = (None, 0) if ym is None else as_nhwc(ym)
-    T = lib.snws_sn_stats_tiles(N, HW, C)
-    part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
-    _launch("sn_bwd_reduce", 2.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_reduce", _ptr(dys), lddy,
-            _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, dt, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(s["beta"]), N, HW, C,
-            int(s["relu"]), _ptr(part), st)
+    fused = fused_bwd_partials(s, dys, lddy) if ym is None else None
+    if fused is not None:
+        part, T = fused
+    else:
+        T = lib.snws_sn_stats_tiles(N, HW, C)
+        part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
+        _launch("sn_bwd_reduce", 2.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_reduce", _ptr(dys), lddy,
+                _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, dt, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(s["beta"]), N, HW, C,
+                int(s["relu"]), _ptr(part), st)
     ctxb = torch.empty(lib.snws_sn_ctxb_floats(N, C), dtype=torch.float32, device=dev)
     packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
     dgamma = grad_out(grad_key(s["gamma"]), (C,), dev)
@@ -543,6 +614,7 @@ class Conv2dwsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, prep, force_direct):
         y, _, saved = conv_forward(x, prep, bias, want_stats=False, force_direct=force_direct)
+        ctx.in_segs = input_segments(x)
         ctx.prep, ctx.saved, ctx.has_bias, ctx.bias_key = prep, saved, bias is not None, grad_key(bias)
         ctx.save_for_backward(weight)
         return y
@@ -551,7 +623,8 @@ class Conv2dwsFn(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key)
+        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
+        ctx.in_segs = None
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db, None, None
@@ -565,6 +638,7 @@ class PlainConvFn(torch.autograd.Function):
         cfg = ConvCfg(weight.shape, 1, (weight.shape[2] - 1) // 2, 1, 1)
         prep = PreparedWeight(weight, cfg, x.dtype == torch.bfloat16, standardize=False)
         y, _, saved = conv_forward(x, prep, bias)
+        ctx.in_segs = input_segments(x)
         ctx.prep, ctx.saved, ctx.has_bias, ctx.bias_key = prep, saved, bias is not None, grad_key(bias)
         ctx.save_for_backward(weight)
         return y
@@ -573,7 +647,8 @@ class PlainConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key)
+        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
+        ctx.in_segs = None
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db
@@ -608,7 +683,7 @@ class ConvSnReluFn(torch.autograd.Function):
                                                                        device=x.device)
         y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift, out=out)
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
-        ctx.bias_key = grad_key(bias)
+        ctx.bias_key, ctx.in_segs = grad_key(bias), input_segments(x)
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.save_for_backward(weight)
         return y
@@ -619,7 +694,8 @@ class ConvSnReluFn(torch.autograd.Function):
         dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn)
         ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key)
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
+        ctx.in_segs = None
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
@@ -640,7 +716,7 @@ class ConvSnAddReluFn(torch.autograd.Function):
                                                                        device=x.device)
         y, sn_saved = sn_forward(conv_out, p, True, stat_part=stat, stat_shift=shift, residual=residual)
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
-        ctx.bias_key = grad_key(bias)
+        ctx.bias_key, ctx.in_segs = grad_key(bias), input_segments(x)
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.res_dtype = residual.dtype
         ctx.save_for_backward(weight)
@@ -656,7 +732,8 @@ class ConvSnAddReluFn(torch.autograd.Function):
             dres = torch.where(y > 0, dy.to(y.dtype), torch.zeros((), dtype=y.dtype, device=y.device)).to(ctx.res_dtype)
         ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key)
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
+        ctx.in_segs = None
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
@@ -686,7 +763,7 @@ class TapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, taps_prep):
         z, _, saved = conv_forward(x, taps_prep.prep, None)
-        ctx.tp, ctx.saved = taps_prep, saved
+        ctx.tp, ctx.saved, ctx.in_segs = taps_prep, saved, input_segments(x)
         ctx.save_for_backward(weight)
         return z
 
@@ -696,7 +773,8 @@ class TapConvFn(torch.autograd.Function):
         tp = ctx.tp
         cfg = tp.cfg
         dx, dwre, _ = conv_backward(dz, tp.prep, ctx.saved, None, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                    False)
+                                    False, None, ctx.in_segs)
+        ctx.in_segs = None
         dw = None
         if dwre is not None:
             g = dwre.view(cfg.kh, cfg.kw, cfg.O, cfg.Ig).permute(2, 0, 1, 3).contiguous()
@@ -766,6 +844,21 @@ class AssembleFn(torch.autograd.Function):
             outs.append(g[:, off:off + c])
             off += c
         return tuple(outs)
+
+
+def assemble(buf, parts):
+    """AssembleFn over the parts written into `buf`, carrying their SwitchNorm tags over to the assembled tensor (at
+    their channel offsets) when every part has one."""
+    y = AssembleFn.apply(buf, *parts)
+    segs, off = [], 0
+    for p in parts:
+        tag = getattr(p, "_snws_seg", None)
+        if not tag:
+            return y
+        segs += [(off + c0, c, s) for c0, c, s in tag]
+        off += p.shape[1]
+    y._snws_seg = segs
+    return y
 
 
 # ------------------------------------------------------------------------------------------------ loss / inference tiles
