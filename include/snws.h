@@ -236,6 +236,14 @@ int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy, const floa
                     int w, int C_out, int k, int ksize, void* stream);
 int snws_upconv_bwd(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dtype, int N, int h, int w, int C_out,
                     int k, int ksize, void* stream);
+/* snws_upconv_fwd that also emits what the SwitchNorm after the block (modeling/UNet3p_SNws.py:29-33) needs:
+ * stat_part [N][T][C_out][2], T = snws_upconv_stat_tiles(h*k, w*k): per 8x32 output strip the sum and the sum of
+ * squares of (y - bias[c]) over the strip's valid pixels, y as stored (rounded) - the layout snws_sn_finalize takes
+ * with shift = bias.  bf16, ksize 3, k in {2,4,8,16}, C_out a multiple of 64 only (else SNWS_ERR_UNSUPPORTED: run
+ * snws_upconv_fwd and snws_sn_stats). */
+int snws_upconv_stat_tiles(int H, int W);
+int snws_upconv_fwd_stats(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, int dtype, int N, int h,
+                          int w, int C_out, int k, int ksize, float* stat_part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused soft-max cross-entropy, forward + backward in one pass - replaces nn.CrossEntropyLoss(ignore_index=255)

@@ -219,6 +219,247 @@ bool launch_fwd_sep(const void* Z, int64_t ldz, void* y, int64_t ldy, const floa
 #undef SEP
 }
 
+// ---- the separable forward with the source footprint staged in LDS (bf16, 3x3, k in {2,4,8,16}, 64-channel chunks).
+// The per-pixel kernels above issue 36 (gather) or ~15 (separable) 16-byte global loads per 8 outputs and run at the
+// L1 rate; here a workgroup copies the footprint of its 8x32 output strip - (8/k + 2..3) x (32/k + 2) source pixels,
+// the three taps of one filter row at a time (192 channels) - global->LDS with 16-byte LDS-DMA loads and every thread
+// reads its operands from there.  Arithmetic and summation order are those of upconv_sep_body, so the two kernels
+// agree bit for bit.  Source pixels are clamped into the image while staging (= the interpolation's border clamp);
+// a 16-byte pad slot per pixel (400-byte pixel stride) spreads the pixels over the LDS banks.
+// Optionally the strip's per-channel sum / sum of squares of the ROUNDED outputs minus the bias are written out, in
+// the layout of the convolution kernels' statistics epilogue, so SwitchNorm does not re-read the tensor.
+template <int K, int PH>
+struct UpStage {
+  static constexpr int FLMIN = up_fl<K>(PH * SEP_TH - 1);
+  static constexpr int R = up_fl<K>(PH * SEP_TH + SEP_TH) + 2 - FLMIN;
+  static constexpr int CW = up_fl<K>(SEP_TW) + 3;          // columns fl(-1) = -1 ... fl(32) + 1
+  static constexpr int QS = 25;                            // 16-byte slots per staged pixel: 3 taps x 8 + 1 pad
+  static constexpr int NS = R * CW * QS;
+  static constexpr int NI = (NS + 63) / 64;                // LDS-DMA instructions per stage (1 KiB each)
+  static constexpr int JN = (NI + 3) / 4;                  // per wave
+  static constexpr int LDS_BYTES = NI * 1024;
+};
+
+__device__ __forceinline__ void up_glds16(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int K, int PH>
+__device__ __forceinline__ void upconv_lds_body(const bf16_t* __restrict__ Z, int64_t ldz, bf16_t* __restrict__ y,
+                                                int64_t ldy, const float* __restrict__ bias, float* __restrict__ stat,
+                                                int h, int w, int Co, int tilesX, unsigned char* smem) {
+  using G = UpStage<K, PH>;
+  constexpr int LOG2K2 = K == 2 ? 2 : K == 4 ? 3 : K == 8 ? 4 : 5;      // log2(2K)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c8 = tid & 7, pxl = tid >> 3;
+  const int tx_ = blockIdx.x % tilesX, cchunk = blockIdx.x / tilesX;
+  const int px0 = tx_ * SEP_TW, px = px0 + pxl, ch = cchunk * 64 + c8 * 8;
+  const int py0 = blockIdx.y * SEP_TH, n = blockIdx.z;
+  const int H = h * K, W = w * K;
+  const int base_lo = (py0 - PH * SEP_TH) / K + G::FLMIN;      // first staged source row (before clamping)
+  const int col_lo = px0 / K - 1;                               // first staged source column (before clamping)
+
+  // per-lane source of every LDS-DMA load of a stage, as a byte offset from the image's tap-row-0 base
+  const unsigned char* zimg = reinterpret_cast<const unsigned char*>(Z + (int64_t)n * h * w * ldz + cchunk * 64);
+  unsigned src[G::JN];
+#pragma unroll
+  for (int j = 0; j < G::JN; ++j) {
+    const int s = (wave + 4 * j) * 64 + lane;
+    const int q = s / G::QS, c = s - q * G::QS;
+    const int qr = q / G::CW, qc = q - qr * G::CW;
+    int row = base_lo + qr, col = col_lo + qc;
+    row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
+    col = col < 0 ? 0 : (col > w - 1 ? w - 1 : col);
+    const int tx = c >> 3, jj = c & 7;
+    const bool real = s < G::NS && c < 24;
+    src[j] = real ? (unsigned)((((int64_t)row * w + col) * ldz + (int64_t)tx * Co + jj * 8) * 2) : 0u;
+  }
+
+  // columns this thread's three filter columns touch: local staged column and interpolation weight
+  int xl[3];
+  float lx[3];
+  bool xok[3];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) {
+    const int qx = px + tx - 1;
+    xok[tx] = qx >= 0 && qx < W && px < W;
+    const int t2 = 2 * qx + 1 - K;                              // (qx + 0.5)/K - 0.5 = t2 / (2K)
+    xl[tx] = (t2 >> LOG2K2) - col_lo;
+    lx[tx] = (float)(t2 & (2 * K - 1)) * (1.f / (float)(2 * K));
+    if (!xok[tx]) xl[tx] = 0;
+  }
+  float out[SEP_TH][8];
+#pragma unroll
+  for (int py = 0; py < SEP_TH; ++py)
+#pragma unroll
+    for (int v = 0; v < 8; ++v) out[py][v] = bias ? bias[ch + v] : 0.f;
+
+#pragma unroll
+  for (int ty = 0; ty < 3; ++ty) {
+    if (ty) __syncthreads();                                    // every wave is done reading the previous stage
+    const unsigned char* zt = zimg + (int64_t)ty * 3 * Co * 2;
+#pragma unroll
+    for (int j = 0; j < G::JN; ++j)
+      if (wave + 4 * j < G::NI) up_glds16(zt + src[j], smem + (wave + 4 * j) * 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    constexpr int dummy = 0; (void)dummy;
+    const int lo = up_fl<K>(PH * SEP_TH + ty - 1) - G::FLMIN, hi = up_fl<K>(PH * SEP_TH + SEP_TH - 1 + ty - 1) + 1 - G::FLMIN;
+    float Gr[G::R][8];
+#pragma unroll
+    for (int rr = 0; rr < G::R; ++rr) {
+      if (rr < lo || rr > hi) continue;
+#pragma unroll
+      for (int v = 0; v < 8; ++v) Gr[rr][v] = 0.f;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        if (!xok[tx]) continue;
+        const unsigned char* pa = smem + ((rr * G::CW + xl[tx]) * G::QS + tx * 8 + c8) * 16;
+        float a[8], b[8];
+        Vec<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(pa), a);
+        Vec<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(pa + G::QS * 16), b);
+        const float w0 = 1.f - lx[tx], w1 = lx[tx];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) Gr[rr][v] += w0 * a[v] + w1 * b[v];
+      }
+    }
+#pragma unroll
+    for (int py = 0; py < SEP_TH; ++py) {
+      const int qy = py0 + py + ty - 1;
+      if (qy < 0 || qy >= H) continue;     // the conv's zero padding
+      const int ia = up_fl<K>(PH * SEP_TH + py + ty - 1) - G::FLMIN;
+      const float lam = up_lam<K>(PH * SEP_TH + py + ty - 1);
+#pragma unroll
+      for (int v = 0; v < 8; ++v) out[py][v] += (1.f - lam) * Gr[ia][v] + lam * Gr[ia + 1][v];
+    }
+  }
+
+  // ---- stores (8 lanes x 16 B = one pixel's 64 channels) and the optional per-channel partial moments
+  float S[8], Q[8], sh[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    S[v] = Q[v] = 0.f;
+    sh[v] = (stat && bias) ? bias[ch + v] : 0.f;
+  }
+  const bool col_ok = px < W;
+#pragma unroll
+  for (int py = 0; py < SEP_TH; ++py) {
+    if (col_ok && py0 + py < H) {
+      uint4 v;
+      v.x = pack_bf16x2(out[py][0], out[py][1]);
+      v.y = pack_bf16x2(out[py][2], out[py][3]);
+      v.z = pack_bf16x2(out[py][4], out[py][5]);
+      v.w = pack_bf16x2(out[py][6], out[py][7]);
+      *reinterpret_cast<uint4*>(y + (((int64_t)n * H + py0 + py) * W + px) * ldy + ch) = v;
+      if (stat) {
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f0 = __uint_as_float(u[e] << 16) - sh[2 * e];
+          const float f1 = __uint_as_float(u[e] & 0xffff0000u) - sh[2 * e + 1];
+          S[2 * e] += f0; Q[2 * e] += f0 * f0;
+          S[2 * e + 1] += f1; Q[2 * e + 1] += f1 * f1;
+        }
+      }
+    }
+  }
+  if (stat) {
+    __syncthreads();                        // the last stage's readers are done: its LDS is reused for the partials
+    float* st_lds = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        S[e] += __shfl_xor(S[e], o, 64);
+        Q[e] += __shfl_xor(Q[e], o, 64);
+      }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        st_lds[(wave * 64 + lane * 8 + e) * 2] = S[e];
+        st_lds[(wave * 64 + lane * 8 + e) * 2 + 1] = Q[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        s += st_lds[(wv * 64 + tid) * 2];
+        q += st_lds[(wv * 64 + tid) * 2 + 1];
+      }
+      const int64_t tile = (int64_t)blockIdx.y * tilesX + tx_;
+      const int64_t T = (int64_t)gridDim.y * tilesX;
+      float* o = stat + (((int64_t)n * T + tile) * Co + cchunk * 64 + tid) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void upconv_fwd_lds_kernel(const bf16_t* __restrict__ Z, int64_t ldz,
+                                                             bf16_t* __restrict__ y, int64_t ldy,
+                                                             const float* __restrict__ bias, float* __restrict__ stat,
+                                                             int h, int w, int Co, int tilesX) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char up_smem[];
+  if constexpr (K == 16) {
+    if (blockIdx.y & 1) upconv_lds_body<K, 1>(Z, ldz, y, ldy, bias, stat, h, w, Co, tilesX, up_smem);
+    else upconv_lds_body<K, 0>(Z, ldz, y, ldy, bias, stat, h, w, Co, tilesX, up_smem);
+  } else {
+    upconv_lds_body<K, 0>(Z, ldz, y, ldy, bias, stat, h, w, Co, tilesX, up_smem);
+  }
+}
+
+template <int K>
+constexpr int up_lds_bytes() {
+  return UpStage<K, 0>::LDS_BYTES > UpStage<K, (K == 16 ? 1 : 0)>::LDS_BYTES ? UpStage<K, 0>::LDS_BYTES
+                                                                             : UpStage<K, (K == 16 ? 1 : 0)>::LDS_BYTES;
+}
+
+// true when the LDS-staged kernel takes this problem
+bool lds_fwd_ok(int dtype, const void* Z, int64_t ldz, const void* y, int64_t ldy, int N, int h, int w, int Co, int k, int ksize) {
+  if (dtype != SNWS_BF16 || ksize != 3 || Co % 64 || ldz % 8 || ldy % 8) return false;
+  if (k != 2 && k != 4 && k != 8 && k != 16) return false;
+  if ((reinterpret_cast<uintptr_t>(Z) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return false;
+  if ((int64_t)h * w * ldz * 2 >= 0xFFFFFFFFll) return false;                  // 32-bit source offsets per image
+  if (cdiv(h * k, SEP_TH) > 65535 || N > 65535) return false;
+  return true;
+}
+
+template <int K>
+int launch_fwd_lds_k(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, float* stat, int N, int h, int w,
+                     int Co, hipStream_t st) {
+  constexpr int LDS = up_lds_bytes<K>() < 2048 ? 2048 : up_lds_bytes<K>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_fwd_lds_kernel<K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      snws_set_error("upconv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int H = h * K, W = w * K;
+  const int tilesX = cdiv(W, SEP_TW), tilesY = cdiv(H, SEP_TH);
+  dim3 grid((unsigned)(tilesX * (Co / 64)), (unsigned)tilesY, (unsigned)N);
+  upconv_fwd_lds_kernel<K><<<grid, 256, LDS, st>>>((const bf16_t*)Z, ldz, (bf16_t*)y, ldy, bias, stat, h, w, Co, tilesX);
+  return SNWS_OK;
+}
+
+int launch_fwd_lds(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, float* stat, int N, int h, int w,
+                   int Co, int k, hipStream_t st) {
+  switch (k) {
+    case 2: return launch_fwd_lds_k<2>(Z, ldz, y, ldy, bias, stat, N, h, w, Co, st);
+    case 4: return launch_fwd_lds_k<4>(Z, ldz, y, ldy, bias, stat, N, h, w, Co, st);
+    case 8: return launch_fwd_lds_k<8>(Z, ldz, y, ldy, bias, stat, N, h, w, Co, st);
+    default: return launch_fwd_lds_k<16>(Z, ldz, y, ldy, bias, stat, N, h, w, Co, st);
+  }
+}
+
 // Backward: one thread per (source pixel, channel group) for ALL taps: every dy value of the (2k+2)^2 window is
 // loaded once and scattered into the taps' register accumulators with separable weights.
 template <typename TZ, typename TY, int V, int KH>
@@ -283,6 +524,107 @@ __global__ __launch_bounds__(256) void upconv_bwd_kernel(const TY* __restrict__ 
   }
 }
 
+// ---- separable backward (bf16, 3x3, k in {2,4,8,16}, channel counts that are multiples of 8).
+// dZ_{ty,tx}(sy,sx) = sum_Y wy(Y+ty-1 -> sy) * Hrow_tx(Y),   Hrow_tx(Y) = sum_X wx(X+tx-1 -> sx) * dy(Y, X):
+// the column weights are the same for every row of the window, so a thread keeps them in registers, reduces each
+// of the 2k+2 window rows to three 8-channel vectors (24 FMAs per loaded value instead of 72) and folds those into
+// the nine tap accumulators.  For k >= 4 the 2k+2 window columns are split over PARTS adjacent lanes; their partial
+// row sums are combined with a butterfly reduce-scatter that leaves lane p with 8/PARTS of the channels, for which
+// it then keeps all nine taps - so no work is duplicated and a thread never walks more than 6 columns per row.
+template <int K, int PARTS>
+__global__ __launch_bounds__(256) void upconv_bwd_sep_kernel(const bf16_t* __restrict__ dy, int64_t lddy,
+                                                             bf16_t* __restrict__ dZ, int64_t lddz, int N, int h, int w,
+                                                             int Co, int64_t total) {
+  constexpr int WIN = 2 * K + 2, CH = (WIN + PARTS - 1) / PARTS, CPP = 8 / PARTS;   // channels per part at the end
+  const int H = h * K, W = w * K, CG = Co / 8;
+  const float inv_k = 1.f / (float)K;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < total;
+  if (!live) idx = total - 1;                       // keep every lane in the shuffles; it just does not store
+  const int part = (int)(idx % PARTS);
+  int64_t r = idx / PARTS;
+  const int cg = (int)(r % CG); r /= CG;
+  const int sx = (int)(r % w); r /= w;
+  const int sy = (int)(r % h);
+  const int n = (int)(r / h);
+  const int X0 = K * sx - K / 2 - 1 + part * CH, Y0 = K * sy - K / 2 - 1;
+  float wx[3][CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int X = X0 + j;
+    const bool in = X >= 0 && X < W && part * CH + j < WIN;
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) wx[tx][j] = in ? tap_weight(X + tx - 1, W, inv_k, w, sx) : 0.f;
+  }
+  float acc[9][CPP];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < CPP; ++v) acc[t][v] = 0.f;
+  const bf16_t* gn = dy + (int64_t)n * H * W * lddy + (int64_t)cg * 8;
+  for (int yi = 0; yi < WIN; ++yi) {
+    const int Y = Y0 + yi;
+    if (Y < 0 || Y >= H) continue;                  // same decision in all PARTS lanes of a source pixel
+    float wy[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) wy[ty] = tap_weight(Y + ty - 1, H, inv_k, h, sy);
+    if (wy[0] == 0.f && wy[1] == 0.f && wy[2] == 0.f) continue;
+    float hv[24];                                   // index v*3 + tx
+#pragma unroll
+    for (int i = 0; i < 24; ++i) hv[i] = 0.f;
+    const bf16_t* row = gn + (int64_t)Y * W * lddy;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int X = X0 + j;
+      if (X < 0 || X >= W || part * CH + j >= WIN) continue;
+      float g[8];
+      Vec<bf16_t, 8>::load(row + (int64_t)X * lddy, g);
+#pragma unroll
+      for (int v = 0; v < 8; ++v)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) hv[v * 3 + tx] = fmaf(wx[tx][j], g[v], hv[v * 3 + tx]);
+    }
+    // butterfly reduce-scatter over the PARTS lanes of this source pixel: lane p ends with channels p*CPP ...
+#pragma unroll
+    for (int o = PARTS / 2, nv = 24; o >= 1; o >>= 1, nv >>= 1) {
+      const bool up = (part & o) != 0;
+#pragma unroll
+      for (int i = 0; i < nv / 2; ++i) {
+        const float lo = hv[i], hi = hv[i + nv / 2];
+        const float recv = __shfl_xor(up ? lo : hi, o, 64);
+        hv[i] = (up ? hi : lo) + recv;
+      }
+    }
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int v = 0; v < CPP; ++v) acc[ty * 3 + tx][v] = fmaf(wy[ty], hv[v * 3 + tx], acc[ty * 3 + tx][v]);
+  }
+  if (!live) return;
+  bf16_t* o = dZ + (((int64_t)n * h + sy) * w + sx) * lddz + (int64_t)cg * 8 + part * CPP;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if constexpr (CPP == 8) {
+      Vec<bf16_t, 8>::store(o + (int64_t)t * Co, acc[t]);
+    } else if constexpr (CPP == 1) {
+      reinterpret_cast<unsigned short*>(o + (int64_t)t * Co)[0] = f32_to_bf16_bits(acc[t][0]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < CPP; v += 2)
+        *reinterpret_cast<unsigned*>(o + (int64_t)t * Co + v) = pack_bf16x2(acc[t][v], acc[t][v + 1]);
+    }
+  }
+}
+
+template <int K, int PARTS>
+void launch_bwd_sep(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int N, int h, int w, int Co, hipStream_t st) {
+  const int64_t total = (int64_t)N * h * w * (Co / 8) * PARTS;
+  upconv_bwd_sep_kernel<K, PARTS><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>((const bf16_t*)dy, lddy, (bf16_t*)dZ, lddz,
+                                                                                N, h, w, Co, total);
+}
+
 unsigned grid_for(int64_t total) {
   int64_t b = cdiv64(total, 256);
   if (b > 262144) b = 262144;
@@ -308,6 +650,12 @@ extern "C" int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy,
   hipStream_t st = (hipStream_t)stream;
   const int64_t pix = (int64_t)N * h * k * w * k;
   static const bool no_sep = getenv("SNWS_UPCONV_GATHER") != nullptr;   // A/B switch: the per-pixel gather kernel
+  static const bool no_lds = getenv("SNWS_UPCONV_NOLDS") != nullptr;    // A/B switch: the kernels without LDS staging
+  if (!no_sep && !no_lds && lds_fwd_ok(dtype, Z, ldz, y, ldy, N, h, w, C_out, k, ksize)) {
+    if (int rc = launch_fwd_lds(Z, ldz, y, ldy, bias, nullptr, N, h, w, C_out, k, st)) return rc;
+    SNWS_LAUNCH_CHECK("snws_upconv_fwd");
+    return SNWS_OK;
+  }
   if (!no_sep && ksize == 3 && C_out % 8 == 0 && ldz % 8 == 0 && ldy % 8 == 0 && al16(Z) && al16(y)) {
     const bool done = dtype == SNWS_F32 ? launch_fwd_sep<float>(Z, ldz, y, ldy, bias, N, h, w, C_out, k, st)
                                         : launch_fwd_sep<bf16_t>(Z, ldz, y, ldy, bias, N, h, w, C_out, k, st);
@@ -331,12 +679,39 @@ extern "C" int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy,
   return SNWS_OK;
 }
 
+extern "C" int snws_upconv_stat_tiles(int H, int W) { return cdiv(H, SEP_TH) * cdiv(W, SEP_TW); }
+
+extern "C" int snws_upconv_fwd_stats(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, int dtype,
+                                     int N, int h, int w, int C_out, int k, int ksize, float* stat_part, void* stream) {
+  if (int rc = check("snws_upconv_fwd_stats", dtype, N, h, w, C_out, k, ksize)) return rc;
+  SNWS_CHECK_ARG(Z && y && stat_part && ldz >= (int64_t)ksize * ksize * C_out && ldy >= C_out,
+                 "snws_upconv_fwd_stats: NULL pointer or bad stride");
+  if (!lds_fwd_ok(dtype, Z, ldz, y, ldy, N, h, w, C_out, k, ksize))
+    SNWS_UNSUPPORTED("snws_upconv_fwd_stats: needs bf16, a 3x3 filter, k in {2,4,8,16}, C_out a multiple of 64 and "
+                     "16-byte aligned tensors (got dtype %d, ksize %d, k %d, C_out %d)", dtype, ksize, k, C_out);
+  if (int rc = launch_fwd_lds(Z, ldz, y, ldy, bias, stat_part, N, h, w, C_out, k, (hipStream_t)stream)) return rc;
+  SNWS_LAUNCH_CHECK("snws_upconv_fwd_stats");
+  return SNWS_OK;
+}
+
 extern "C" int snws_upconv_bwd(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dtype, int N, int h, int w,
                                int C_out, int k, int ksize, void* stream) {
   if (int rc = check("snws_upconv_bwd", dtype, N, h, w, C_out, k, ksize)) return rc;
   SNWS_CHECK_ARG(dy && dZ && lddz >= (int64_t)ksize * ksize * C_out && lddy >= C_out, "snws_upconv_bwd: NULL pointer or bad stride");
   hipStream_t st = (hipStream_t)stream;
   const int64_t items = (int64_t)N * h * w;
+  static const bool no_sep_bwd = getenv("SNWS_UPCONV_BWD_GATHER") != nullptr;   // A/B switch: the non-separable kernel
+  if (!no_sep_bwd && dtype == SNWS_BF16 && ksize == 3 && C_out % 8 == 0 && lddz % 8 == 0 && lddy % 8 == 0 && al16(dZ) &&
+      al16(dy) && (k == 2 || k == 4 || k == 8 || k == 16) && cdiv64(items * (C_out / 8) * 8, 256) < (1ll << 31)) {
+    switch (k) {
+      case 2: launch_bwd_sep<2, 1>(dy, lddy, dZ, lddz, N, h, w, C_out, st); break;
+      case 4: launch_bwd_sep<4, 2>(dy, lddy, dZ, lddz, N, h, w, C_out, st); break;
+      case 8: launch_bwd_sep<8, 4>(dy, lddy, dZ, lddz, N, h, w, C_out, st); break;
+      default: launch_bwd_sep<16, 8>(dy, lddy, dZ, lddz, N, h, w, C_out, st); break;
+    }
+    SNWS_LAUNCH_CHECK("snws_upconv_bwd");
+    return SNWS_OK;
+  }
 #define UPB(TT, VV, KK) upconv_bwd_kernel<TT, TT, VV, KK><<<grid_for(items * (C_out / VV)), 256, 0, st>>>((const TT*)dy, lddy, (TT*)dZ, lddz, N, h, w, C_out, k)
   if (dtype == SNWS_F32) {
     const bool vec = C_out % 4 == 0 && lddz % 4 == 0 && lddy % 4 == 0 && al16(dZ) && al16(dy);

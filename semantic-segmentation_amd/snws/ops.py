@@ -798,9 +798,21 @@ class UpTapSnReluFn(torch.autograd.Function):
         conv_out = new_nhwc(N, c_out, h * k, w * k, z.dtype, z.device)
         b32 = None if bias is None else _f32c(bias)
         work = float(z.element_size()) * N * c_out * (h * w * ksize * ksize + h * k * w * k)
-        _launch("upconv_fwd", work, "snws_upconv_fwd", _ptr(zs), ldz, _ptr(conv_out), c_out, _ptr(b32), dtype_code(z), N,
-                h, w, c_out, k, ksize, _stream())
-        y, sn_saved = sn_forward(conv_out, p, relu, out=out)
+        stat = shift = None
+        if z.dtype == torch.bfloat16 and ksize == 3 and c_out % 64 == 0 and k in (2, 4, 8, 16) and ldz % 8 == 0:
+            # the LDS-staged kernel also hands SwitchNorm the per-strip moments of its (rounded) output
+            T = L.lib().snws_upconv_stat_tiles(h * k, w * k)
+            stat = torch.empty((N, T, c_out, 2), dtype=torch.float32, device=z.device)
+            try:
+                _launch("upconv_fwd", work, "snws_upconv_fwd_stats", _ptr(zs), ldz, _ptr(conv_out), c_out, _ptr(b32),
+                        dtype_code(z), N, h, w, c_out, k, ksize, _ptr(stat), _stream())
+                shift = b32 if b32 is not None else torch.zeros(c_out, dtype=torch.float32, device=z.device)
+            except L.SnwsUnsupported:
+                stat = None
+        if stat is None:
+            _launch("upconv_fwd", work, "snws_upconv_fwd", _ptr(zs), ldz, _ptr(conv_out), c_out, _ptr(b32), dtype_code(z),
+                    N, h, w, c_out, k, ksize, _stream())
+        y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift, out=out)
         ctx.sn, ctx.meta, ctx.has_bias = sn_saved, (N, h, w, k, ksize, c_out, CZ), bias is not None
         ctx.bias_key = grad_key(bias)
         ctx.shapes = (gamma.shape, beta.shape)

@@ -1146,3 +1146,127 @@ def test_fused_sn_bwd_model_gradients_match_unfused():
     print("fused vs unfused SwitchNorm backward: per-layer partial sums max rel diff %.2e; parameter gradients "
           "median %.2e worst %.2e" % (max(layer_err), statistics.median(errs), max(errs)))
     assert statistics.median(errs) < 2e-2 and max(errs) < 0.15
+
+
+# ================================================================== LDS-staged up-sampled-conv forward (+ statistics)
+@pytest.mark.gpu
+def test_upconv_lds_kernel_matches_unstaged_and_emits_stats():
+    """The LDS-staged forward (bf16, 3x3, 64-channel chunks; the default where it applies) against the kernels
+    without LDS staging (SNWS_UPCONV_NOLDS=1, read once per process, hence the child process): same arithmetic in
+    the same order for k >= 8 (bit-exact), bf16-rounding-level agreement with the per-pixel kernel for k = 2, 4.
+    Sizes include strips cut by the image border, one-pixel sources and 128 channels.  snws_upconv_fwd_stats must
+    store the same y and per-strip sums that add up to the moments of (y - bias) recomputed from y."""
+    import subprocess
+    import tempfile
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join(%r, "semantic-segmentation_amd"))
+from snws import _lib as L
+out = {}
+torch.manual_seed(0)
+for k, h, w, Co in ((2, 3, 5, 64), (2, 20, 37, 64), (4, 3, 2, 64), (4, 9, 17, 128), (8, 2, 5, 64), (8, 5, 9, 64),
+                    (16, 1, 3, 64), (16, 3, 4, 128), (2, 1, 1, 64), (16, 1, 1, 64)):
+    Z = torch.randn(2, h, w, 9 * Co, device="cuda").to(torch.bfloat16)
+    b = torch.randn(Co, device="cuda")
+    y = torch.empty(2, h * k, w * k, Co, device="cuda", dtype=torch.bfloat16)
+    L.call("snws_upconv_fwd", Z.data_ptr(), 9 * Co, y.data_ptr(), Co, b.data_ptr(), 1, 2, h, w, Co, k, 3, 0)
+    torch.cuda.synchronize()
+    out["k%%d_%%d_%%d_%%d" %% (k, h, w, Co)] = y.float().cpu().numpy()
+np.savez(sys.argv[1], **out)
+""" % ROOT
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, env_extra in enumerate(({"SNWS_UPCONV_NOLDS": "1"}, {})):
+            env = dict(os.environ)
+            env.pop("SNWS_UPCONV_NOLDS", None)
+            env.update(env_extra)
+            path = os.path.join(d, "o%d.npz" % i)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=200)
+            res.append(dict(np.load(path)))
+    assert set(res[0]) == set(res[1]) and len(res[0]) == 10
+    for key in res[0]:
+        a, b = res[0][key], res[1][key]
+        k = int(key[1:].split("_")[0])
+        if k >= 8:
+            assert np.array_equal(a, b), key
+        else:       # the unstaged default for k < 8 is the per-pixel kernel: other summation order, then bf16 rounding
+            assert np.abs(a - b).max() <= 2 ** -7 * np.abs(a).max(), key
+    # statistics entry point
+    from snws import _lib as L
+    lib = L.lib()
+    torch.manual_seed(1)
+    for k, h, w, Co in ((2, 20, 37, 64), (4, 9, 17, 128), (16, 3, 4, 64)):
+        N, H, W = 2, h * k, w * k
+        Z = torch.randn(N, h, w, 9 * Co, device=DEV).to(torch.bfloat16)
+        b = torch.randn(Co, device=DEV)
+        y0 = torch.empty(N, H, W, Co, device=DEV, dtype=torch.bfloat16)
+        y1 = torch.empty_like(y0)
+        T = lib.snws_upconv_stat_tiles(H, W)
+        part = torch.full((N, T, Co, 2), float("nan"), device=DEV)
+        L.call("snws_upconv_fwd", Z.data_ptr(), 9 * Co, y0.data_ptr(), Co, b.data_ptr(), 1, N, h, w, Co, k, 3, 0)
+        L.call("snws_upconv_fwd_stats", Z.data_ptr(), 9 * Co, y1.data_ptr(), Co, b.data_ptr(), 1, N, h, w, Co, k, 3,
+               part.data_ptr(), 0)
+        assert torch.equal(y0, y1)
+        d = y1.double() - b.double()
+        s_ref = torch.stack([d.sum((1, 2)), (d * d).sum((1, 2))], -1)
+        got = part.double().sum(1)
+        assert torch.isfinite(part).all()
+        assert float((got - s_ref).abs().max()) < 1e-5 * float(s_ref.abs().max())
+    with pytest.raises(L.SnwsUnsupported):
+        Z = torch.randn(1, 2, 2, 9 * 16, device=DEV).to(torch.bfloat16)
+        y = torch.empty(1, 4, 4, 16, device=DEV, dtype=torch.bfloat16)
+        part = torch.empty(1, 1, 16, 2, device=DEV)
+        L.call("snws_upconv_fwd_stats", Z.data_ptr(), 144, y.data_ptr(), 16, None, 1, 1, 2, 2, 16, 2, 3, part.data_ptr(), 0)
+
+
+@pytest.mark.gpu
+def test_upconv_separable_backward_matches_gather_backward():
+    """The separable backward (bf16, 3x3; window columns split over 1/2/4/8 lanes for k = 2/4/8/16) against the
+    per-source-pixel gather kernel (SNWS_UPCONV_BWD_GATHER=1, read once per process, hence the child process): the
+    same f32 sums in another order, then one bf16 rounding.  Odd sizes, one-pixel sources, 8..128 channels, a
+    strided dZ; plus the adjoint identity <up(Z), dy> = <Z, up^T(dy)> against the forward kernel."""
+    import subprocess
+    import tempfile
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join(%r, "semantic-segmentation_amd"))
+from snws import _lib as L
+out = {}
+torch.manual_seed(0)
+for k, h, w, Co in ((2, 3, 5, 8), (2, 20, 37, 64), (4, 3, 2, 16), (4, 9, 17, 128), (8, 2, 5, 64), (8, 5, 9, 24),
+                    (16, 1, 3, 64), (16, 3, 4, 16), (2, 1, 1, 64), (16, 1, 1, 8), (4, 1, 7, 64)):
+    dy = torch.randn(2, h * k, w * k, Co, device="cuda").to(torch.bfloat16)
+    dZ = torch.zeros(2, h, w, 9 * Co + 8, device="cuda", dtype=torch.bfloat16)
+    L.call("snws_upconv_bwd", dy.data_ptr(), Co, dZ.data_ptr(), 9 * Co + 8, 1, 2, h, w, Co, k, 3, 0)
+    torch.cuda.synchronize()
+    out["k%%d_%%d_%%d_%%d" %% (k, h, w, Co)] = dZ.float().cpu().numpy()
+np.savez(sys.argv[1], **out)
+""" % ROOT
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, env_extra in enumerate(({"SNWS_UPCONV_BWD_GATHER": "1"}, {})):
+            env = dict(os.environ)
+            env.pop("SNWS_UPCONV_BWD_GATHER", None)
+            env.update(env_extra)
+            path = os.path.join(d, "o%d.npz" % i)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=200)
+            res.append(dict(np.load(path)))
+    assert set(res[0]) == set(res[1]) and len(res[0]) == 11
+    for key in res[0]:
+        a, b = res[0][key], res[1][key]
+        assert np.all(b[..., -8:] == 0), key                      # the stride padding is left alone
+        assert np.abs(a - b).max() <= 2 ** -7 * np.abs(a).max(), (key, np.abs(a - b).max(), np.abs(a).max())
+    # adjoint identity in this process (default kernels), f64 inner products of the bf16 tensors
+    from snws import _lib as L
+    torch.manual_seed(2)
+    for k, h, w, Co in ((2, 6, 9, 64), (4, 5, 3, 64), (8, 3, 2, 64), (16, 2, 2, 64)):
+        Z = torch.randn(1, h, w, 9 * Co, device=DEV).to(torch.bfloat16)
+        dy = torch.randn(1, h * k, w * k, Co, device=DEV).to(torch.bfloat16)
+        y = torch.empty_like(dy)
+        dZ = torch.empty_like(Z)
+        L.call("snws_upconv_fwd", Z.data_ptr(), 9 * Co, y.data_ptr(), Co, None, 1, 1, h, w, Co, k, 3, 0)
+        L.call("snws_upconv_bwd", dy.data_ptr(), Co, dZ.data_ptr(), 9 * Co, 1, 1, h, w, Co, k, 3, 0)
+        lhs = float((y.double() * dy.double()).sum())
+        rhs = float((Z.double() * dZ.double()).sum())
+        scale = float(y.double().norm() * dy.double().norm())
+        assert abs(lhs - rhs) < 5e-3 * scale, (k, lhs, rhs, scale)
