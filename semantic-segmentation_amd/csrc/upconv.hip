@@ -400,7 +400,7 @@ __device__ __forceinline__ void upconv_lds_body(const bf16_t* __restrict__ Z, in
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void upconv_fwd_lds_kernel(const bf16_t* __restrict__ Z, int64_t ldz,
+__global__ __launch_bounds__(256, (K == 4 || K == 8) ? 2 : 3) void upconv_fwd_lds_kernel(const bf16_t* __restrict__ Z, int64_t ldz,
                                                              bf16_t* __restrict__ y, int64_t ldy,
                                                              const float* __restrict__ bias, float* __restrict__ stat,
                                                              int h, int w, int Co, int tilesX) {
@@ -562,28 +562,44 @@ __global__ __launch_bounds__(256) void upconv_bwd_sep_kernel(const bf16_t* __res
 #pragma unroll
     for (int v = 0; v < CPP; ++v) acc[t][v] = 0.f;
   const bf16_t* gn = dy + (int64_t)n * H * W * lddy + (int64_t)cg * 8;
-  for (int yi = 0; yi < WIN; ++yi) {
-    const int Y = Y0 + yi;
-    if (Y < 0 || Y >= H) continue;                  // same decision in all PARTS lanes of a source pixel
-    float wy[3];
+  // the window rows inside the image, software-pipelined: row y+1 is in flight while row y is reduced
+  const int ya = Y0 < 0 ? 0 : Y0, yb = Y0 + WIN - 1 > H - 1 ? H - 1 : Y0 + WIN - 1;
+  bool cok[CH];
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty) wy[ty] = tap_weight(Y + ty - 1, H, inv_k, h, sy);
-    if (wy[0] == 0.f && wy[1] == 0.f && wy[2] == 0.f) continue;
-    float hv[24];                                   // index v*3 + tx
-#pragma unroll
-    for (int i = 0; i < 24; ++i) hv[i] = 0.f;
+  for (int j = 0; j < CH; ++j) cok[j] = X0 + j >= 0 && X0 + j < W && part * CH + j < WIN;
+  uint4 cur[CH], nxt[CH];
+  auto load_row = [&](int Y, uint4 (&dst)[CH]) {
     const bf16_t* row = gn + (int64_t)Y * W * lddy;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int X = X0 + j;
-      if (X < 0 || X >= W || part * CH + j >= WIN) continue;
-      float g[8];
-      Vec<bf16_t, 8>::load(row + (int64_t)X * lddy, g);
-#pragma unroll
-      for (int v = 0; v < 8; ++v)
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx) hv[v * 3 + tx] = fmaf(wx[tx][j], g[v], hv[v * 3 + tx]);
+      dst[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (cok[j]) dst[j] = *reinterpret_cast<const uint4*>(row + (int64_t)(X0 + j) * lddy);
     }
+  };
+  if (ya <= yb) load_row(ya, cur);
+  for (int Y = ya; Y <= yb; ++Y) {
+    if (Y < yb) load_row(Y + 1, nxt);
+    float wy[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) wy[ty] = tap_weight(Y + ty - 1, H, inv_k, h, sy);
+    float hv[24];                                   // index v*3 + tx
+#pragma unroll
+    for (int i = 0; i < 24; ++i) hv[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const unsigned u[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g0 = __uint_as_float(u[e] << 16), g1 = __uint_as_float(u[e] & 0xffff0000u);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          hv[(2 * e) * 3 + tx] = fmaf(wx[tx][j], g0, hv[(2 * e) * 3 + tx]);
+          hv[(2 * e + 1) * 3 + tx] = fmaf(wx[tx][j], g1, hv[(2 * e + 1) * 3 + tx]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
     // butterfly reduce-scatter over the PARTS lanes of this source pixel: lane p ends with channels p*CPP ...
 #pragma unroll
     for (int o = PARTS / 2, nv = 24; o >= 1; o >>= 1, nv >>= 1) {
