@@ -1103,7 +1103,7 @@ extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, cons
   // 650 -> 813 TFLOP/s, 128->128 @256^2 703 -> 924 with one round; 320->320 @512^2 prefers 2048: 1057 vs 981.)
   static const int forced_blocks = getenv("SNWS_WGRAD_BLOCKS") ? atoi(getenv("SNWS_WGRAD_BLOCKS")) : 0;
   const int target_blocks = forced_blocks > 0 ? forced_blocks : ((int64_t)ntiles * npairs >= 32ll * 2048 ? 2048 : 512);
-  int splits = target_blocks >= 2048 ? cdiv(target_blocks, npairs) : target_blocks / npairs;
+  int splits = target_blocks / npairs;   // never more than target_blocks workgroups: two extra ones cost a whole extra round
   if (splits < 1) splits = 1;
   if (splits > ntiles) splits = ntiles;
   a.tilesPerSplit = cdiv(ntiles, splits);

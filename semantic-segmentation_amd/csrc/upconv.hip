@@ -219,12 +219,23 @@ bool launch_fwd_sep(const void* Z, int64_t ldz, void* y, int64_t ldy, const floa
 #undef SEP
 }
 
+
+// v_dot2c_f32_bf16: acc + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (products exact, f32 accumulation); with
+// v_perm_b32 to pair up the same channel of two pixels it halves the ALU work of unpack + 2 FMA per pair.
+typedef __attribute__((ext_vector_type(2))) __bf16 up_bf16x2;
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(up_bf16x2, a), __builtin_bit_cast(up_bf16x2, b), acc, false);
+}
+// (a.lo, b.lo) and (a.hi, b.hi) as packed pairs: element 0 from a, element 1 from b
+__device__ __forceinline__ unsigned pair_lo(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ unsigned pair_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
 // ---- the separable forward with the source footprint staged in LDS (bf16, 3x3, k in {2,4,8,16}, 64-channel chunks).
 // The per-pixel kernels above issue 36 (gather) or ~15 (separable) 16-byte global loads per 8 outputs and run at the
 // L1 rate; here a workgroup copies the footprint of its 8x32 output strip - (8/k + 2..3) x (32/k + 2) source pixels,
 // the three taps of one filter row at a time (192 channels) - global->LDS with 16-byte LDS-DMA loads and every thread
-// reads its operands from there.  Arithmetic and summation order are those of upconv_sep_body, so the two kernels
-// agree bit for bit.  Source pixels are clamped into the image while staging (= the interpolation's border clamp);
+// reads its operands from there; the column interpolation runs on packed bf16 pairs (v_dot2c_f32_bf16: exact products,
+// f32 accumulation), the row interpolation in f32 as in upconv_sep_body.  Source pixels are clamped into the image while staging (= the interpolation's border clamp);
 // a 16-byte pad slot per pixel (400-byte pixel stride) spreads the pixels over the LDS banks.
 // Optionally the strip's per-channel sum / sum of squares of the ROUNDED outputs minus the bias are written out, in
 // the layout of the convolution kernels' statistics epilogue, so SwitchNorm does not re-read the tensor.
@@ -289,6 +300,9 @@ __device__ __forceinline__ void upconv_lds_body(const bf16_t* __restrict__ Z, in
     lx[tx] = (float)(t2 & (2 * K - 1)) * (1.f / (float)(2 * K));
     if (!xok[tx]) xl[tx] = 0;
   }
+  unsigned wpk[3];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) wpk[tx] = pack_bf16x2(1.f - lx[tx], lx[tx]);
   float out[SEP_TH][8];
 #pragma unroll
   for (int py = 0; py < SEP_TH; ++py)
@@ -316,12 +330,13 @@ __device__ __forceinline__ void upconv_lds_body(const bf16_t* __restrict__ Z, in
       for (int tx = 0; tx < 3; ++tx) {
         if (!xok[tx]) continue;
         const unsigned char* pa = smem + ((rr * G::CW + xl[tx]) * G::QS + tx * 8 + c8) * 16;
-        float a[8], b[8];
-        Vec<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(pa), a);
-        Vec<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(pa + G::QS * 16), b);
-        const float w0 = 1.f - lx[tx], w1 = lx[tx];
+        const uint4 ua = *reinterpret_cast<const uint4*>(pa), ub = *reinterpret_cast<const uint4*>(pa + G::QS * 16);
+        const unsigned a4[4] = {ua.x, ua.y, ua.z, ua.w}, b4[4] = {ub.x, ub.y, ub.z, ub.w};
 #pragma unroll
-        for (int v = 0; v < 8; ++v) Gr[rr][v] += w0 * a[v] + w1 * b[v];
+        for (int e = 0; e < 4; ++e) {       // (1 - lx) * a + lx * b per channel: the two weights are exact in bf16
+          Gr[rr][2 * e] = dot2_bf16(pair_lo(a4[e], b4[e]), wpk[tx], Gr[rr][2 * e]);
+          Gr[rr][2 * e + 1] = dot2_bf16(pair_hi(a4[e], b4[e]), wpk[tx], Gr[rr][2 * e + 1]);
+        }
       }
     }
 #pragma unroll
@@ -400,7 +415,7 @@ __device__ __forceinline__ void upconv_lds_body(const bf16_t* __restrict__ Z, in
 }
 
 template <int K>
-__global__ __launch_bounds__(256, (K == 4 || K == 8) ? 2 : 3) void upconv_fwd_lds_kernel(const bf16_t* __restrict__ Z, int64_t ldz,
+__global__ __launch_bounds__(256, 3) void upconv_fwd_lds_kernel(const bf16_t* __restrict__ Z, int64_t ldz,
                                                              bf16_t* __restrict__ y, int64_t ldy,
                                                              const float* __restrict__ bias, float* __restrict__ stat,
                                                              int h, int w, int Co, int tilesX) {
@@ -548,13 +563,22 @@ __global__ __launch_bounds__(256) void upconv_bwd_sep_kernel(const bf16_t* __res
   const int sy = (int)(r % h);
   const int n = (int)(r / h);
   const int X0 = K * sx - K / 2 - 1 + part * CH, Y0 = K * sy - K / 2 - 1;
-  float wx[3][CH];
+  // column weights of two neighbouring window columns, packed as bf16 pairs (multiples of 1/(2K): exact)
+  constexpr int CP = (CH + 1) / 2;
+  unsigned wxp[3][CP];
 #pragma unroll
-  for (int j = 0; j < CH; ++j) {
-    const int X = X0 + j;
-    const bool in = X >= 0 && X < W && part * CH + j < WIN;
+  for (int jp = 0; jp < CP; ++jp) {
 #pragma unroll
-    for (int tx = 0; tx < 3; ++tx) wx[tx][j] = in ? tap_weight(X + tx - 1, W, inv_k, w, sx) : 0.f;
+    for (int tx = 0; tx < 3; ++tx) {
+      float wv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j = 2 * jp + u, X = X0 + j;
+        const bool in = j < CH && X >= 0 && X < W && part * CH + j < WIN;
+        wv[u] = in ? tap_weight(X + tx - 1, W, inv_k, w, sx) : 0.f;
+      }
+      wxp[tx][jp] = pack_bf16x2(wv[0], wv[1]);
+    }
   }
   float acc[9][CPP];
 #pragma unroll
@@ -564,15 +588,15 @@ __global__ __launch_bounds__(256) void upconv_bwd_sep_kernel(const bf16_t* __res
   const bf16_t* gn = dy + (int64_t)n * H * W * lddy + (int64_t)cg * 8;
   // the window rows inside the image, software-pipelined: row y+1 is in flight while row y is reduced
   const int ya = Y0 < 0 ? 0 : Y0, yb = Y0 + WIN - 1 > H - 1 ? H - 1 : Y0 + WIN - 1;
-  bool cok[CH];
+  bool cok[2 * CP];
 #pragma unroll
-  for (int j = 0; j < CH; ++j) cok[j] = X0 + j >= 0 && X0 + j < W && part * CH + j < WIN;
-  uint4 cur[CH], nxt[CH];
-  auto load_row = [&](int Y, uint4 (&dst)[CH]) {
+  for (int j = 0; j < 2 * CP; ++j) cok[j] = j < CH && X0 + j >= 0 && X0 + j < W && part * CH + j < WIN;
+  uint4 cur[2 * CP], nxt[2 * CP];
+  auto load_row = [&](int Y, uint4 (&dst)[2 * CP]) {
     const bf16_t* row = gn + (int64_t)Y * W * lddy;
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      dst[j] = make_uint4(0u, 0u, 0u, 0u);
+    for (int j = 0; j < 2 * CP; ++j) {
+      dst[j] = make_uint4(0u, 0u, 0u, 0u);       // a column outside the window or the image counts as zeros
       if (cok[j]) dst[j] = *reinterpret_cast<const uint4*>(row + (int64_t)(X0 + j) * lddy);
     }
   };
@@ -586,20 +610,21 @@ __global__ __launch_bounds__(256) void upconv_bwd_sep_kernel(const bf16_t* __res
 #pragma unroll
     for (int i = 0; i < 24; ++i) hv[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const unsigned u[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+    for (int jp = 0; jp < CP; ++jp) {
+      const unsigned ua[4] = {cur[2 * jp].x, cur[2 * jp].y, cur[2 * jp].z, cur[2 * jp].w};
+      const unsigned ub[4] = {cur[2 * jp + 1].x, cur[2 * jp + 1].y, cur[2 * jp + 1].z, cur[2 * jp + 1].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float g0 = __uint_as_float(u[e] << 16), g1 = __uint_as_float(u[e] & 0xffff0000u);
+        const unsigned lo = pair_lo(ua[e], ub[e]), hi = pair_hi(ua[e], ub[e]);   // one channel of both columns
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
-          hv[(2 * e) * 3 + tx] = fmaf(wx[tx][j], g0, hv[(2 * e) * 3 + tx]);
-          hv[(2 * e + 1) * 3 + tx] = fmaf(wx[tx][j], g1, hv[(2 * e + 1) * 3 + tx]);
+          hv[(2 * e) * 3 + tx] = dot2_bf16(lo, wxp[tx][jp], hv[(2 * e) * 3 + tx]);
+          hv[(2 * e + 1) * 3 + tx] = dot2_bf16(hi, wxp[tx][jp], hv[(2 * e + 1) * 3 + tx]);
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
+    for (int j = 0; j < 2 * CP; ++j) cur[j] = nxt[j];
     // butterfly reduce-scatter over the PARTS lanes of this source pixel: lane p ends with channels p*CPP ...
 #pragma unroll
     for (int o = PARTS / 2, nv = 24; o >= 1; o >>= 1, nv >>= 1) {

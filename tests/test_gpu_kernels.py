@@ -1152,8 +1152,8 @@ def test_fused_sn_bwd_model_gradients_match_unfused():
 @pytest.mark.gpu
 def test_upconv_lds_kernel_matches_unstaged_and_emits_stats():
     """The LDS-staged forward (bf16, 3x3, 64-channel chunks; the default where it applies) against the kernels
-    without LDS staging (SNWS_UPCONV_NOLDS=1, read once per process, hence the child process): same arithmetic in
-    the same order for k >= 8 (bit-exact), bf16-rounding-level agreement with the per-pixel kernel for k = 2, 4.
+    without LDS staging (SNWS_UPCONV_NOLDS=1, read once per process, hence the child process): agreement to one bf16
+    rounding of the output.
     Sizes include strips cut by the image border, one-pixel sources and 128 channels.  snws_upconv_fwd_stats must
     store the same y and per-strip sums that add up to the moments of (y - bias) recomputed from y."""
     import subprocess
@@ -1186,11 +1186,8 @@ np.savez(sys.argv[1], **out)
     assert set(res[0]) == set(res[1]) and len(res[0]) == 10
     for key in res[0]:
         a, b = res[0][key], res[1][key]
-        k = int(key[1:].split("_")[0])
-        if k >= 8:
-            assert np.array_equal(a, b), key
-        else:       # the unstaged default for k < 8 is the per-pixel kernel: other summation order, then bf16 rounding
-            assert np.abs(a - b).max() <= 2 ** -7 * np.abs(a).max(), key
+        # other summation order (and packed-pair dot products for the column stage), then one bf16 rounding
+        assert np.abs(a - b).max() <= 2 ** -7 * np.abs(a).max(), key
     # statistics entry point
     from snws import _lib as L
     lib = L.lib()
