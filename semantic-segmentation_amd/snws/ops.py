@@ -65,7 +65,32 @@ def grad_out(key, shape, device, zero=False):
         sink[3][0] = True
         flat, off, n = sink[:3]
         return flat[off:off + n].view(shape)
-    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=device)
+    t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=device)
+    if sink is not None and sink[3][0] and sink[2] == _numel(shape):
+        _FOLD[id(t)] = (t, sink)        # a further use of the parameter in this step: grad_fold adds it into the slot
+    return t
+
+
+_FOLD = {}
+
+
+def grad_fold(t):
+    """Call on a tensor obtained from grad_out once its kernel has been enqueued, and return the result to autograd.
+    The first gradient of a parameter in a step lives in its flat slot and is returned as is; a further one (a
+    module used at several places) is added into the slot here and None is returned, so autograd neither sums nor
+    copies anything for that parameter."""
+    if t is None:
+        return None
+    entry = _FOLD.pop(id(t), None)
+    if entry is None:
+        return t
+    flat, off, n = entry[1][:3]
+    flat[off:off + n].view(t.shape).add_(t)
+    return None
+
+
+def _view(t, shape):
+    return None if t is None else t.view(shape)
 
 
 def _numel(shape):
@@ -349,7 +374,7 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=N
             w32 = (w32 if w32.dtype == torch.float32 else w32.float()).contiguous()
             dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), dev)
             L.call("snws_ws_bwd", _ptr(w32), _ptr(g), ldg, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
-    return dx, dw, db
+    return dx, grad_fold(dw), grad_fold(db)
 
 
 # ------------------------------------------------------------------------------------------------ SwitchNorm
@@ -513,8 +538,8 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None):
             s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C,
             int(s["relu"]), st)
     if want_dx_sum:
-        return dx, dgamma, dbeta, dmw, dvw, dxsum
-    return dx, dgamma, dbeta, dmw, dvw
+        return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw), grad_fold(dxsum)
+    return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw)
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm
@@ -584,7 +609,7 @@ def bn_backward(dy, s):
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
     _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]),
             s["ldx"], None, 0, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C, int(s["relu"]), st)
-    return dx, dgamma, dbeta
+    return dx, grad_fold(dgamma), grad_fold(dbeta)
 
 
 class BatchNormFn(torch.autograd.Function):
@@ -603,7 +628,7 @@ class BatchNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         dx, dg, db = bn_backward(dy, ctx.s)
         ctx.s = None
-        return (dx, dg.view(ctx.shapes[0]) if ctx.has[0] else None, db.view(ctx.shapes[1]) if ctx.has[1] else None,
+        return (dx, _view(dg, ctx.shapes[0]) if ctx.has[0] else None, _view(db, ctx.shapes[1]) if ctx.has[1] else None,
                 None, None, None, None, None, None, None, None, None)
 
 
@@ -667,7 +692,7 @@ class SwitchNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         dx, dg, db, dmw, dvw = sn_backward(dy, ctx.s)
-        return dx, dg.view(ctx.shapes[0]), db.view(ctx.shapes[1]), dmw, dvw, None, None
+        return dx, _view(dg, ctx.shapes[0]), _view(db, ctx.shapes[1]), dmw, dvw, None, None
 
 
 class ConvSnReluFn(torch.autograd.Function):
@@ -699,7 +724,7 @@ class ConvSnReluFn(torch.autograd.Function):
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
-        return dx, dw, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None, None
+        return dx, dw, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, None, None, None, None
 
 
 class ConvSnAddReluFn(torch.autograd.Function):
@@ -737,7 +762,7 @@ class ConvSnAddReluFn(torch.autograd.Function):
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
-        return dx, dw, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, dres
+        return dx, dw, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, None, None, dres
 
 
 # ------------------------------------------------------------------------------------------------ conv of an up-sampled map
@@ -781,7 +806,9 @@ class TapConvFn(torch.autograd.Function):
             w32 = _f32c(weight)
             dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), g.device)
             L.call("snws_ws_bwd", _ptr(w32), _ptr(g), cfg.Ig, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
-            dw = dw.to(weight.dtype)
+            dw = grad_fold(dw)
+            if dw is not None:
+                dw = dw.to(weight.dtype)
         ctx.saved = None
         return dx, dw, None
 
@@ -828,7 +855,7 @@ class UpTapSnReluFn(torch.autograd.Function):
         _launch("upconv_bwd", work, "snws_upconv_bwd", _ptr(dconv), c_out, _ptr(dz), CZ, dtype_code(dconv), N, h, w,
                 c_out, k, ksize, _stream())
         db = dxsum if ctx.has_bias else None
-        return dz, db, dg.view(ctx.shapes[0]), dbeta.view(ctx.shapes[1]), dmw, dvw, None, None, None, None, None, None
+        return dz, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, None, None, None, None, None, None
 
 
 class AssembleFn(torch.autograd.Function):
