@@ -694,6 +694,150 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// 1x1 wgrad over 64-wide channel tiles.  In the generic kernel a wave owns a 32x32 corner of the (out, in) tile and
+// reads two LDS fragments per MFMA, which asks the LDS for more than it delivers.  Here the four waves split the
+// PIXELS of a tile (four of its sixteen 16-pixel k-steps each) and every wave accumulates the whole 64x64 tile: two
+// dy and two x fragments feed four MFMAs.  The waves' partial tiles are summed through LDS before the atomic flush.
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad1_kernel(WgradArgs a) {
+  using G = WgGeom<64, 1>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* dy_lds = smem;
+  unsigned char* x_lds = smem + G::DY_BYTES;
+  float* b_lds = reinterpret_cast<float*>(smem + G::DY_BYTES + ((G::X_BYTES + 15) / 16) * 16);   // [4 waves][64 channels]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int npairs = a.coTiles * a.ciTiles;
+  const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = bid % npairs, split = bid / npairs;
+  const int cot = pair % a.coTiles, cit = pair / a.coTiles;
+  const int ntiles = a.N * a.tilesY * a.tilesX;
+  const int t_begin = split * a.tilesPerSplit;
+  const int t_end = t_begin + a.tilesPerSplit < ntiles ? t_begin + a.tilesPerSplit : ntiles;
+  const bool want_bias = BIAS && cit == 0;
+
+  f32x16 acc[2][2];   // [out-channel half][in-channel half]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+  if (want_bias) b_lds[tid] = 0.f;   // ordered before its first use by the barrier that follows the first staging
+
+  // transposing-read lane geometry (see the generic kernel).  Pixel p of k-step ks: p = 16*ks + kb + gq (+4 for the
+  // second half); its chunk swizzle bit (p >> 1) & 1 only depends on kb + gq.
+  const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
+  const int rb = (grp & 1) * 16, kb = (grp >> 1) * 8;
+  const int cb0 = kb + gq;
+  const unsigned char *abase[2], *bbase[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int ch = h * 32 + rb + 4 * gp;
+    const int off = (wave * 64 + cb0) * 128 + (((ch >> 3) ^ (((cb0 >> 1) & 1) << 2)) * 16) + (ch & 7) * 2;
+    abase[h] = dy_lds + off;
+    bbase[h] = x_lds + off;
+  }
+  // staging: lane = (pixel q of a piece's 8, 16-byte chunk c); piece i holds pixels 8i .. 8i+7
+  const int st_q = lane >> 3, st_chunk = (lane & 7) ^ (((st_q >> 1) & 1) << 2);
+  const bool st_dy_ok = cot * 64 + st_chunk * 8 < a.Cout, st_x_ok = cit * 64 + st_chunk * 8 < a.Cin;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    int tt = t;
+    const int tx = tt % a.tilesX; tt /= a.tilesX;
+    const int ty = tt % a.tilesY;
+    const int n = tt / a.tilesY;
+    const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+#pragma unroll
+    for (int j = 0; j < G::JD; ++j) {       // piece wave + 4j = tile row j, columns 8*wave .. 8*wave+7
+      const int gy = y0 + j, gx = x0 + wave * 8 + st_q;
+      const bool in = gy < a.H && gx < a.W;
+      const int64_t pix = ((int64_t)n * a.H + gy) * a.W + gx;
+      const void* sd = (in && st_dy_ok) ? (const void*)(a.dy + pix * a.lddy + cot * 64 + st_chunk * 8) : (const void*)snws_zero_page;
+      const void* sx = (in && st_x_ok) ? (const void*)(a.x + pix * a.ldx + cit * 64 + st_chunk * 8) : (const void*)snws_zero_page;
+      glds16(sd, dy_lds + (wave + 4 * j) * 1024);
+      glds16(sx, x_lds + (wave + 4 * j) * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (want_bias) {  // bias gradient: column sums of the dy tile, kept per wave in LDS (block-uniform branch)
+      const int c8 = tid & 7;
+      float bs[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pix = (tid >> 3) + 32 * j;
+        float f[8];
+        Vec<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(dy_lds + pix * 128 + ((c8 ^ (((pix >> 1) & 1) << 2)) * 16)), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] += f[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = bs[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 8) b_lds[wave * 64 + lane * 8 + e] += v;
+      }
+    }
+
+    // this wave's four k-steps (pixels 64*wave .. 64*wave+63), fragments of step s+1 read while step s multiplies
+    bf16x8 af[2][2], bf[2][2];
+    auto load_step = [&](int s) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        af[s & 1][h] = tr_frag(abase[h] + s * 2048, abase[h] + s * 2048 + 512);
+        bf[s & 1][h] = tr_frag(bbase[h] + s * 2048, bbase[h] + s * 2048 + 512);
+      }
+    };
+    load_step(0);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      if (s_ + 1 < 4) load_step(s_ + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s_ & 1][i], bf[s_ & 1][h], acc[i][h], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- sum the four waves' partial tiles through LDS (the staging buffers are free now: the loop's last barrier
+  //      ordered every read), then one atomic flush: D[row = out channel][col = in channel]
+  float* red = reinterpret_cast<float*>(smem);            // [4 waves][4 quadrants][16 regs][64 lanes] = 64 KB
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * 4 + i * 2 + h) * 16 + r) * 64 + lane] = acc[i][h][r];
+  float bias_sum = 0.f;
+  if (want_bias && tid < 64) bias_sum = b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192];
+  __syncthreads();
+  // wave w flushes quadrant w (i = w >> 1, h = w & 1)
+  {
+    const int i = wave >> 1, h = wave & 1;
+    const int ci = cit * 64 + h * 32 + (lane & 31);
+    const bool ci_ok = ci < a.Cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[((w * 4 + wave) * 16 + r) * 64 + lane];
+      const int co = cot * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (ci_ok && co < a.Cout) atomicAdd(a.dw + (int64_t)co * a.Cin + ci, v);
+    }
+  }
+  if (want_bias && tid < 64 && cot * 64 + tid < a.Cout) atomicAdd(a.dbias + cot * 64 + tid, bias_sum);
+}
+
 // 3x3 wgrad over 64-wide in-channel tiles.  The generic kernel above reads one B fragment from LDS per MFMA, which
 // asks the LDS for its full 128 B/clk at the matrix pipe's peak rate.  Here a wave owns ALL 64 out channels (two A
 // fragments) x one 32-wide in-channel half x a group of 5 or 4 taps, so every B fragment feeds two MFMAs (7
@@ -1039,6 +1183,24 @@ int launch_wgrad(const WgradArgs& a, unsigned grid, hipStream_t st) {
 }
 
 template <bool BIAS>
+int launch_wgrad1(const WgradArgs& a, unsigned grid, hipStream_t st) {
+  constexpr int LDS = WgGeom<64, 1>::LDS_BYTES > 65536 + 1024 ? WgGeom<64, 1>::LDS_BYTES : 65536 + 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1_kernel<BIAS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  conv_wgrad1_kernel<BIAS><<<grid, 256, LDS, st>>>(a);
+  SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
+  return SNWS_OK;
+}
+
+template <bool BIAS>
 int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<64, 9>;
   static bool attr_set = false;
@@ -1116,6 +1278,10 @@ extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, cons
     if (generic) return launch_wgrad<64, 9>(a, grid, st);
     return dbias ? launch_wgrad9<true>(a, grid, st) : launch_wgrad9<false>(a, grid, st);
   }
-  if (c64) return launch_wgrad<64, 1>(a, grid, st);
+  if (c64) {
+    static const bool generic1 = getenv("SNWS_WGRAD_GENERIC") != nullptr;
+    if (generic1) return launch_wgrad<64, 1>(a, grid, st);
+    return dbias ? launch_wgrad1<true>(a, grid, st) : launch_wgrad1<false>(a, grid, st);
+  }
   return taps == 9 ? launch_wgrad<16, 9>(a, grid, st) : launch_wgrad<16, 1>(a, grid, st);
 }

@@ -230,6 +230,8 @@ MFMA_CASES = [
     (1, 320, 320, 16, 32, 3),   # 5 output tiles, 10 chunks
     (2, 64, 128, 17, 33, 3),    # odd sizes: partial tiles in both directions
     (1, 64, 64, 32, 64, 1),     # 1x1
+    (2, 320, 144, 19, 37, 1),   # 1x1, channel tails in both tile directions, ragged pixel tiles
+    (1, 1024, 576, 8, 8, 1),    # 1x1, many tile pairs, one pixel tile
     (1, 32, 24, 8, 8, 3),       # C_out not a multiple of 64 (direct wgrad), tiny map
 ]
 
