@@ -82,7 +82,7 @@ def grad_fold(t):
     if t is None:
         return None
     entry = _FOLD.pop(id(t), None)
-    if entry is None:
+    if entry is None or entry[0] is not t:
         return t
     flat, off, n = entry[1][:3]
     flat[off:off + n].view(t.shape).add_(t)
