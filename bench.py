@@ -7,9 +7,10 @@ batch 16 per GPU, synthetic FY-4A-shaped tiles, data-parallel over N GPUs of one
 
 A step = zero_grad -> forward -> CE/N loss -> backward -> (bucketed gradient all-reduce) -> AdamW step with the poly
 LR, i.e. Trainer.training's inner loop.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
-line.  `roofline` is for the dominant kernel (the 3x3 MFMA implicit-GEMM kernel that runs forward and dgrad):
-algorithmic FLOPs of its launches / their HIP-event durations inside the timed region, against the dense bf16 MFMA
-peak.  `cpu_baseline` times the CPU oracle (a port of the reference's arithmetic) on rank 0's host cores on a bounded
+line.  `roofline` is for the dominant kernel (the 3x3 MFMA implicit-GEMM kernel conv_fwd_kernel<32,9,...> that runs
+forward and dgrad, in both of its epilogue variants): algorithmic FLOPs of its launches / their HIP-event durations
+inside the timed region, against the dense bf16 MFMA peak.  (`kernels` lists the variants separately:
+conv_mfma_dgradsn_* are the dgrad launches whose epilogue also runs the SwitchNorm backward reduction.)  `cpu_baseline` times the CPU oracle (a port of the reference's arithmetic) on rank 0's host cores on a bounded
 sample of the same workload.
 """
 import argparse
@@ -160,7 +161,8 @@ def main():
         loss = trainer.step(img, lab)
     barrier()
     ops.PROFILE = None if args.no_kernel_events else []
-    ops.PROFILE_ONLY = None if args.all_kernel_events else ("conv_mfma_fwd_k3_kc32", "conv_mfma_dgrad_k3_kc32")
+    ops.PROFILE_ONLY = None if args.all_kernel_events else ("conv_mfma_fwd_k3_kc32", "conv_mfma_dgrad_k3_kc32",
+                                                            "conv_mfma_dgradsn_k3_kc32")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(img, lab)
@@ -185,7 +187,8 @@ def main():
             k[0] += 1
             k[1] += work
             k[2] += e0.elapsed_time(e1) * 1e-3
-        fam = [v for t, v in kernels.items() if t in ("conv_mfma_fwd_k3_kc32", "conv_mfma_dgrad_k3_kc32")]
+        fam = [v for t, v in kernels.items() if t in ("conv_mfma_fwd_k3_kc32", "conv_mfma_dgrad_k3_kc32",
+                                                    "conv_mfma_dgradsn_k3_kc32")]
         roofline = None
         if fam:
             fl, tt, cnt = sum(v[1] for v in fam), sum(v[2] for v in fam), sum(v[0] for v in fam)
@@ -198,7 +201,7 @@ def main():
                 with open(pmc_file) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
                 tsrc = "profiles/r01_pmc_bench_conv.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-            roofline = {"bound": "mfma", "kernel": "conv_fwd_kernel<KC=32,TAPS=9> (forward + dgrad launches)",
+            roofline = {"bound": "mfma", "kernel": "conv_fwd_kernel<KC=32,TAPS=9> (forward + dgrad launches, both epilogue variants)",
                         "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "launches": cnt,
                         "avg_launch_ms": tt / cnt * 1e3, "flops_per_launch": fl / cnt}

@@ -69,8 +69,10 @@ struct FwdArgs {
   int N, H, W, Cout;
   int64_t ldx, ldy;
   int tilesX, tilesY, coTiles, nchunks;
-  int nbwr;                       // > 0: bwr[0 .. coTiles) is valid
-  SnBwdTile bwr[MAX_BWR_TILES];
+};
+// arguments of the dgrad variant whose epilogue also reduces for the SwitchNorm layers behind its output
+struct FwdArgsBwr : FwdArgs {
+  SnBwdTile bwr[MAX_BWR_TILES];   // [0 .. coTiles) is valid
 };
 
 constexpr int FWD_TH = 16, FWD_TW = 32;
@@ -108,8 +110,10 @@ __device__ __forceinline__ int col_swz(int px) {
 //             MFMAs and retired by a counted s_waitcnt + raw s_barrier, so staging overlaps the matrix work.
 // M16      : v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (KC = 32 only).  Same FLOPs per cycle and the same LDS
 //             bytes per FLOP, but the chip holds a higher clock under this shape.
-template <int KC, int TAPS, bool DB, bool M16>
-__global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kernel(FwdArgs a) {
+// BWR      : the dgrad + SwitchNorm-backward-reduction variant (its own kernel, so a profile lists it separately).
+template <int KC, int TAPS, bool DB, bool M16, bool BWR = false>
+__global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kernel(
+    std::conditional_t<BWR, FwdArgsBwr, FwdArgs> a) {
   static_assert(!M16 || KC == 32, "the 16x16x32 shape contracts 32 channels per instruction");
   using G = FwdGeom<KC, TAPS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -317,11 +321,13 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
   const int rows = a.H - y0 < FWD_TH ? a.H - y0 : FWD_TH;      // block-uniform
   // A dgrad launch that also reduces for a SwitchNorm layer needs that layer's input at the pixels this thread will
   // store: all 16 loads are issued here, so their latency overlaps the accumulator write-out and the barrier.
-  const bool bw = a.nbwr > 0 && a.bwr[ct].part != nullptr;     // block-uniform
-  const bool bwc = bw && j8 * 8 < a.bwr[ct].cvalid && gxs < a.W;
+  const SnBwdTile* gt = nullptr;
+  if constexpr (BWR) gt = &a.bwr[ct];
+  const bool bw = BWR && gt->part != nullptr;     // block-uniform
+  const bool bwc = bw && j8 * 8 < gt->cvalid && gxs < a.W;
   uint4 xin[16];
   if (bw) {
-    const SnBwdTile& g = a.bwr[ct];
+    const SnBwdTile& g = *gt;
     if (bwc) {
       const bf16_t* bx = g.x + (((int64_t)n * a.H + y0) * a.W + gxs) * g.ldx + j8 * 8;
       const int64_t bstep = (int64_t)a.W * g.ldx;
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
     // (the output tile itself is stored at the very end: loads and stores share one in-flight counter and may
     // complete out of order with respect to each other, so a wait for xin[i] issued after a store would also drain
     // the stores - and so would the barrier of the cross-wave reduction below)
-    const SnBwdTile& g = a.bwr[ct];
+    const SnBwdTile& g = *gt;
     float mu[8], sc[8], be[8], rs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
     const int64_t T = (int64_t)a.tilesX * a.tilesY;
     float* o = nullptr;
     if (bw) {
-      if (tid < a.bwr[ct].cvalid) o = a.bwr[ct].part + (((int64_t)n * T + tile) * a.bwr[ct].cseg + tid) * 2;
+      if (tid < gt->cvalid) o = gt->part + (((int64_t)n * T + tile) * gt->cseg + tid) * 2;
     } else if (tid < 64 && co0 + tid < a.Cout) {
       o = a.stat + (((int64_t)n * T + tile) * a.Cout + co0 + tid) * 2;
     }
@@ -1080,13 +1086,13 @@ int conv_db_mode() {
   return mode;
 }
 
-template <int KC, int TAPS, bool DB, bool M16>
-int launch_fwd_v(const FwdArgs& a, unsigned grid, hipStream_t st) {
+template <int KC, int TAPS, bool DB, bool M16, bool BWR>
+int launch_fwd_v(const std::conditional_t<BWR, FwdArgsBwr, FwdArgs>& a, unsigned grid, hipStream_t st) {
   using G = FwdGeom<KC, TAPS>;
   constexpr int LDS = DB ? G::LDS_BYTES_DB : G::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<KC, TAPS, DB, M16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<KC, TAPS, DB, M16, BWR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1094,25 +1100,31 @@ int launch_fwd_v(const FwdArgs& a, unsigned grid, hipStream_t st) {
     }
     attr_set = true;
   }
-  conv_fwd_kernel<KC, TAPS, DB, M16><<<grid, 256, LDS, st>>>(a);
+  conv_fwd_kernel<KC, TAPS, DB, M16, BWR><<<grid, 256, LDS, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_fwd");
   return SNWS_OK;
 }
 
 // SNWS_CONV_DB = 0/1 forces the single- / double-buffered kernel, SNWS_CONV_M16 = 0/1 the MFMA shape; unset = the
 // measured best per shape
-template <int KC, int TAPS>
-int launch_fwd(const FwdArgs& a, unsigned grid, hipStream_t st) {
+template <int KC, int TAPS, bool BWR>
+int launch_fwd(const std::conditional_t<BWR, FwdArgsBwr, FwdArgs>& a, unsigned grid, hipStream_t st) {
   const int mode = conv_db_mode();
   const bool db = (mode >= 0 ? mode == 1 : TAPS == 1) && a.nchunks >= 2;   // pays for 1x1 (short chunks), loses for 3x3
   if constexpr (KC == 32) {
     static const int m16_env = getenv("SNWS_CONV_M16") ? atoi(getenv("SNWS_CONV_M16")) : -1;
     const bool m16 = m16_env >= 0 ? m16_env != 0 : true;   // +13% over 32x32x16 at equal cycles (higher sustained clock)
-    if (db) return m16 ? launch_fwd_v<32, TAPS, true, true>(a, grid, st) : launch_fwd_v<32, TAPS, true, false>(a, grid, st);
-    return m16 ? launch_fwd_v<32, TAPS, false, true>(a, grid, st) : launch_fwd_v<32, TAPS, false, false>(a, grid, st);
+    if (db) return m16 ? launch_fwd_v<32, TAPS, true, true, BWR>(a, grid, st) : launch_fwd_v<32, TAPS, true, false, BWR>(a, grid, st);
+    return m16 ? launch_fwd_v<32, TAPS, false, true, BWR>(a, grid, st) : launch_fwd_v<32, TAPS, false, false, BWR>(a, grid, st);
   } else {
-    return launch_fwd_v<KC, TAPS, false, false>(a, grid, st);
+    return launch_fwd_v<KC, TAPS, false, false, BWR>(a, grid, st);
   }
+}
+
+template <bool BWR>
+int launch_fwd_any(const std::conditional_t<BWR, FwdArgsBwr, FwdArgs>& a, int kc, int taps, unsigned grid, hipStream_t st) {
+  if (kc == 32) return taps == 9 ? launch_fwd<32, 9, BWR>(a, grid, st) : launch_fwd<32, 1, BWR>(a, grid, st);
+  return taps == 9 ? launch_fwd<16, 9, BWR>(a, grid, st) : launch_fwd<16, 1, BWR>(a, grid, st);
 }
 
 // runs y(C_out_run channels) = conv(x(C_in_run channels), pack)
@@ -1123,11 +1135,11 @@ int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_ru
   SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)pack & 15) == 0,
                  "%s: pointers must be 16-byte aligned", fn);
   const PackGeom g = pack_geom(c_in_run, c_out_run, taps);
-  FwdArgs a;
+  FwdArgsBwr a;
   a.x = (const bf16_t*)x; a.pack = (const bf16_t*)pack; a.bias = bias; a.y = (bf16_t*)y; a.stat = stat;
   a.N = N; a.H = H; a.W = W; a.Cout = c_out_run; a.ldx = ldx; a.ldy = ldy;
   a.tilesX = cdiv(W, FWD_TW); a.tilesY = cdiv(H, FWD_TH); a.coTiles = g.c_out_p / 64; a.nchunks = g.nchunks;
-  a.nbwr = 0;
+  bool bwr = false;
   if (n_segs > 0) {
     if (a.coTiles > MAX_BWR_TILES) SNWS_UNSUPPORTED("%s: more than %d output-channel tiles", fn, MAX_BWR_TILES * 64);
     for (int t = 0; t < MAX_BWR_TILES; ++t) a.bwr[t] = SnBwdTile{};
@@ -1156,12 +1168,12 @@ int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_ru
         tl.relu = sg.relu;
       }
     }
-    a.nbwr = a.coTiles;
+    bwr = true;
   }
   const int64_t nblk = (int64_t)N * a.tilesX * a.tilesY * a.coTiles;
   SNWS_CHECK_ARG(nblk < (1ll << 31), "%s: grid too large", fn);
-  if (g.KC == 32) return taps == 9 ? launch_fwd<32, 9>(a, (unsigned)nblk, st) : launch_fwd<32, 1>(a, (unsigned)nblk, st);
-  return taps == 9 ? launch_fwd<16, 9>(a, (unsigned)nblk, st) : launch_fwd<16, 1>(a, (unsigned)nblk, st);
+  if (bwr) return launch_fwd_any<true>(a, g.KC, taps, (unsigned)nblk, st);
+  return launch_fwd_any<false>(static_cast<const FwdArgs&>(a), g.KC, taps, (unsigned)nblk, st);
 }
 
 template <int CIC, int TAPS>

@@ -286,7 +286,8 @@ def input_segments(x):
 
 
 def _launch_dgrad(cfg, d, dys, prep, dxp, segs, N, H, W, flops):
-    tag = "conv_mfma_dgrad_k%d_kc%d" % (cfg.kh, 32 if cfg.O % 32 == 0 else 16)
+    kc = 32 if cfg.O % 32 == 0 else 16
+    tag = "conv_mfma_dgrad_k%d_kc%d" % (cfg.kh, kc)
     if not segs:
         _launch(tag, flops, "snws_conv_mfma_dgrad", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), _stream())
         return
@@ -298,7 +299,7 @@ def _launch_dgrad(cfg, d, dys, prep, dxp, segs, N, H, W, flops):
         parts.append(part)
         arr[i] = L.SnBwdSeg(c0, c, s["xs"].data_ptr(), s["ldx"], s["ctx"].data_ptr(), s["beta"].data_ptr(),
                             part.data_ptr(), int(s["relu"]))
-    _launch(tag, flops, "snws_conv_mfma_dgrad_sn", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), arr,
+    _launch("conv_mfma_dgradsn_k%d_kc%d" % (cfg.kh, kc), flops, "snws_conv_mfma_dgrad_sn", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(dxp), arr,
             len(segs), _stream())
     for (c0, c, s), part in zip(segs, parts):
         # (partials, tiles, the gradient buffer - kept alive so its address cannot be recycled -, its version, channel)

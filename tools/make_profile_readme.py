@@ -31,12 +31,15 @@ out = ["# profiles/", "",
 if pmc:
     out.append("* `%s` - rocprofv3 `--pmc` passes (separate runs) for the dominant kernel on the 320->320 @512^2 layer." % os.path.basename(pmc))
 r = b.get("roofline") or {}
-dom = [x for x in rows if "conv_fwd_kernel<32, 9" in x["Name"]]
+dom = [x for x in rows if "conv_fwd_kernel<32, 9, false, true, " in x["Name"]]
 if dom and r:
-    out += ["", "The dominant kernel `conv_fwd_kernel<32, 9, ...>` (3x3 MFMA implicit GEMM, forward + dgrad launches) averages "
-            "%.1f us per launch in the rocprofv3 trace; `bench.py`'s HIP events measured %.1f us for the same launches "
-            "(%.0f TFLOP/s = %.3f of the 2500 TFLOP/s dense bf16 peak)."
-            % (float(dom[0]["AverageNs"]) / 1e3, r["avg_launch_ms"] * 1e3, r["achieved"], r["frac"])]
+    calls = sum(int(x["Calls"]) for x in dom)
+    avg = sum(float(x["TotalDurationNs"]) for x in dom) / calls / 1e3
+    out += ["", "The dominant kernel `conv_fwd_kernel<32, 9, false, true, *>` (3x3 MFMA implicit GEMM; `..., false>` = forward and "
+            "plain dgrad launches, `..., true>` = dgrad launches whose epilogue also runs the SwitchNorm backward reduction) "
+            "averages %.1f us per launch over its %d launches in the rocprofv3 trace; `bench.py`'s HIP events measured %.1f us "
+            "for the same launches (%.0f TFLOP/s = %.3f of the 2500 TFLOP/s dense bf16 peak)."
+            % (avg, calls, r["avg_launch_ms"] * 1e3, r["achieved"], r["frac"])]
 out += ["", "GPU time per step %.1f ms (sum of kernel durations / %d steps)." % (tot / steps / 1e6, steps), "",
         "| kernel | calls | ms / step | avg us | % of GPU time |", "|---|---|---|---|---|"]
 for x in rows[:28]:

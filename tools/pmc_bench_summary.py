@@ -4,7 +4,7 @@ tools/run_pmc_bench.sh.  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE
 bytes, so it is doubled.  Writes gpurun_out/pmc_bench/summary.json (copy it to profiles/)."""
 import csv, glob, json, sys
 d = sys.argv[1]
-KEY = "conv_fwd_kernel<32, 9"
+KEY = "conv_fwd_kernel<32, 9, false, true, "     # both epilogue variants (plain, and dgrad + SwitchNorm reduction)
 res = {}
 for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     vals = []
@@ -16,7 +16,7 @@ for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 n = len(res["FETCH_SIZE"])
 fetch = 2.0 * 1024.0 * sum(res["FETCH_SIZE"]) / max(n, 1)
 write = 1024.0 * sum(res["WRITE_SIZE"]) / max(len(res["WRITE_SIZE"]), 1)
-out = {"kernel": "conv_fwd_kernel<32, 9, ...> (forward + dgrad launches of 3 training steps)", "launches": n,
+out = {"kernel": "conv_fwd_kernel<32, 9, false, true, *> (forward + dgrad launches of 3 training steps, both epilogue variants)", "launches": n,
        "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
        "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); Infinity-Cache hits are included"}
 json.dump(out, open(d + "/summary.json", "w"), indent=1)
