@@ -11,14 +11,17 @@
 //   the 16 lanes of a ds_read_b128 group hit 16 distinct bank slots; the swizzle is applied to the per-lane
 //   SOURCE address because LDS-DMA writes lane-linearly.  Two workgroups per CU (76.8 KB LDS each) overlap one
 //   block's staging with the other's MFMAs.
-//   Epilogue: accumulators (+bias) -> bf16 -> LDS -> 128-byte-per-pixel coalesced stores, plus optional
-//   per-tile sum / sum-of-squares of the ROUNDED outputs per channel, which SwitchNorm consumes instead of
-//   re-reading the tensor.
+//   Epilogue: accumulators (+bias) -> bf16 -> LDS -> 128-byte-per-pixel coalesced stores (issued last: nothing in
+//   the workgroup waits for them), plus optional per-tile sum / sum-of-squares of the ROUNDED outputs per channel,
+//   which SwitchNorm consumes instead of re-reading the tensor.  The BWR instantiation (dgrad only) instead reduces,
+//   per tile, what pass 1 of the backward of the SwitchNorm(+ReLU) layers behind the gradient needs (sum g,
+//   sum g * xhat with g masked by the recomputed ReLU), reading those layers' inputs for the tile it is storing.
 //
 // Wgrad: D[out channel][in channel] = sum over pixels; both operands are needed pixel-major per lane, so the
 //   NHWC tiles are read from LDS with the transposing ds_read_b64_tr_b16.  A workgroup owns a 64x64 (out,in)
 //   filter tile for all taps (144 accumulator registers per lane), sweeps a slice of the pixel tiles, and adds
-//   its result to the f32 gradient with float atomics (128-byte segments per wave-instruction).
+//   its result to the f32 gradient with float atomics (128-byte segments per wave-instruction).  3x3 and 1x1 have
+//   their own kernels (conv_wgrad9_kernel, conv_wgrad1_kernel); the generic one serves C_in = 16.
 #include "common.h"
 #include "pack.h"
 #include <stdlib.h>
