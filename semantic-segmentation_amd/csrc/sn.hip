@@ -140,10 +140,19 @@ __global__ __launch_bounds__(512) void sn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
   double S = 0, Q = 0;
   if (c < C) {
-    for (int t = tl; t < T; t += 8) {
-      const float* p = part + (((int64_t)n * T + t) * C + c) * 2;
-      S += (double)p[0];
-      Q += (double)p[1];
+    // four independent loads in flight per thread (the loop is latency-bound: 16 workgroups read the whole buffer)
+    const float2* p = reinterpret_cast<const float2*>(part) + ((int64_t)n * T) * C + c;
+    int t = tl;
+    for (; t + 24 < T; t += 32) {
+      const float2 v0 = p[(int64_t)t * C], v1 = p[(int64_t)(t + 8) * C], v2 = p[(int64_t)(t + 16) * C],
+                   v3 = p[(int64_t)(t + 24) * C];
+      S += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      Q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; t < T; t += 8) {
+      const float2 v = p[(int64_t)t * C];
+      S += (double)v.x;
+      Q += (double)v.y;
     }
   }
   red[0][tl][cl] = S;
@@ -429,10 +438,18 @@ __global__ __launch_bounds__(512) void sn_bwd_mix_a1_kernel(const float* __restr
   const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
   double P = 0, Q = 0;
   if (c < C) {
-    for (int t = tl; t < T; t += 8) {
-      const float* p = part + (((int64_t)n * T + t) * C + c) * 2;
-      P += (double)p[0];
-      Q += (double)p[1];
+    const float2* p = reinterpret_cast<const float2*>(part) + ((int64_t)n * T) * C + c;
+    int t = tl;
+    for (; t + 24 < T; t += 32) {       // four independent loads in flight per thread
+      const float2 v0 = p[(int64_t)t * C], v1 = p[(int64_t)(t + 8) * C], v2 = p[(int64_t)(t + 16) * C],
+                   v3 = p[(int64_t)(t + 24) * C];
+      P += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      Q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; t < T; t += 8) {
+      const float2 v = p[(int64_t)t * C];
+      P += (double)v.x;
+      Q += (double)v.y;
     }
   }
   red[0][tl][cl] = P;
@@ -495,7 +512,6 @@ __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restr
                                                             float* __restrict__ dmw, float* __restrict__ dvw,
                                                             float* __restrict__ dxsum, int N, int64_t HW, int C,
                                                             float Ng, int training, int using_bn) {
-  __shared__ double scratch[16];
   const CtxOff o = ctx_off(N, C);
   const CtxbOff ob = ctxb_off(N, C);
   const int K = using_bn ? 3 : 2;
@@ -537,9 +553,32 @@ __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restr
     // sum over the plane of dx = A*dy' + B*x + K is A*P + dmean_in; parked in the (now consumed) dm slot
     ctxb[ob.dm + i] = ctx[o.scale + i] * ctxb[ob.P + i] + dmean_in;
   }
-  for (int k = 0; k < 3; ++k) {
-    da[k] = block_sum(da[k], scratch);
-    db[k] = block_sum(db[k], scratch);
+  {   // the six sums in one round trip through LDS
+    __shared__ double red6[6][16];
+    const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      da[k] = wave_sum(da[k]);
+      db[k] = wave_sum(db[k]);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        red6[k][wid] = da[k];
+        red6[3 + k][wid] = db[k];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double sa = 0, sb = 0;
+      for (int i = 0; i < nw; ++i) {
+        sa += red6[k][i];
+        sb += red6[3 + k][i];
+      }
+      da[k] = sa;
+      db[k] = sb;
+    }
   }
   if (dxsum) {
     __syncthreads();
