@@ -10,7 +10,8 @@ LR, i.e. Trainer.training's inner loop.  Inputs are resident in HBM before the t
 line.  `roofline` is for the dominant kernel (the 3x3 MFMA implicit-GEMM kernel conv_fwd_kernel<32,9,...> that runs
 forward and dgrad, in both of its epilogue variants): algorithmic FLOPs of its launches / their HIP-event durations
 inside the timed region, against the dense bf16 MFMA peak.  (`kernels` lists the variants separately:
-conv_mfma_dgradsn_* are the dgrad launches whose epilogue also runs the SwitchNorm backward reduction.)  `cpu_baseline` times the CPU oracle (a port of the reference's arithmetic) on rank 0's host cores on a bounded
+conv_mfma_dgradsn_* are the dgrad launches whose epilogue also runs the SwitchNorm backward reduction.)
+`cpu_baseline` times the CPU oracle (a port of the reference's arithmetic) on rank 0's host cores on a bounded
 sample of the same workload.
 """
 import argparse
