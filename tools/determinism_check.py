@@ -47,5 +47,28 @@ with torch.no_grad():
             bad += 1
             print("MISMATCH model forward rep", rep, float((ref - out).abs().max()))
             break
-print("model forward repeatable" if not bad else "FAILURES: %d" % bad)
+# fused blocks: forward (up-sampled conv from LDS + statistics), and the backward chain whose dgrad epilogue feeds the
+# SwitchNorm reduction; everything but the weight gradients (float atomics) must repeat bit for bit
+from modeling.blocks import ConvSnRelu  # noqa: E402
+torch.manual_seed(3)
+b1, b2 = ConvSnRelu(64, 64).to(DEV).train(), ConvSnRelu(64, 64).to(DEV).train()
+for k in (2, 4, 8, 16):
+    x = torch.randn(2, 64, 64 // k * 2, 64 // k * 2, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    ref = None
+    for rep in range(10):
+        x.grad = None
+        ops.FUSED_SN_BWD_HITS = 0
+        y = b2(b1.on_upsampled(x, k))
+        g = torch.ones_like(y) * 0.01
+        y.backward(g)
+        cur = (y.detach().float().clone(), x.grad.float().clone())
+        if ref is None:
+            ref, hits = cur, ops.FUSED_SN_BWD_HITS
+        elif not (torch.equal(ref[0], cur[0]) and torch.equal(ref[1], cur[1])):
+            bad += 1
+            print("MISMATCH fused chain k", k, "rep", rep)
+            break
+    print("upconv k%d -> conv chain repeatable (fused SwitchNorm reductions: %d)" % (k, hits))
+print("all repeatable" if not bad else "FAILURES: %d" % bad)
 sys.exit(1 if bad else 0)
