@@ -64,9 +64,10 @@ int snws_conv_pack(const float* w, int O, int I, int kh, int kw, float* w_ohwi, 
                    void* stream);
 
 /* dw (O,I,kh,kw) f32 = gradient w.r.t. the master weight given g = dL/d(what) stored as (O, kh, kw, ldg)
- * with ldg >= I (the wgrad kernels' output layout). */
+ * with ldg >= I (the wgrad kernels' output layout).  accumulate != 0: dw += (a module used at several places
+ * in one step); 0: dw is overwritten. */
 int snws_ws_bwd(const float* w, const float* g_ohwi, int64_t ldg, float* dw, int O, int I, int kh, int kw,
-                void* stream);
+                int accumulate, void* stream);
 
 /* Bytes of one MFMA operand image for a conv with these channel counts / kernel size. */
 int64_t snws_conv_pack_bytes(int c_in, int c_out, int kh, int kw);
@@ -171,18 +172,19 @@ int64_t snws_sn_ctxb_floats(int N, int C);
 int snws_sn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask, int64_t ldy,
                        int dtype, const float* ctx, const float* gamma, const float* beta, int N, int64_t HW, int C,
                        int relu, float* part, void* stream);
-/* Partials -> dm, dv per (n,c); per-image and per-channel sums; dgamma/dbeta (C) overwritten;
- * packb (2C) = [sum_n dm, sum_n dv] is the backward all-reduce payload. */
+/* Partials -> dm, dv per (n,c); per-image and per-channel sums; dgamma/dbeta (C) overwritten (accumulate == 0) or
+ * added to (accumulate != 0); packb (2C) = [sum_n dm, sum_n dv] is the backward all-reduce payload. */
 int snws_sn_bwd_mix_a(const float* part, int T, const float* ctx, const float* gamma, float* ctxb, float* packb,
-                      float* dgamma, float* dbeta, int N, int C, void* stream);
+                      float* dgamma, float* dbeta, int N, int C, int accumulate, void* stream);
 /* After the caller's all-reduce of packb: coefficients A,B,K of dx = A*dy' + B*x + K into ctxb, and the
- * gradients of mean_weight / var_weight (overwritten, 3 or 2 entries).  n_global = global batch size.
- * dx_sum (nullable, C floats, overwritten): sum of dx over (n, pixels) per channel in closed form - the gradient
- * of a per-channel bias added before the normalisation (the conv bias of a ConvSnRelu block). */
+ * gradients of mean_weight / var_weight (3 or 2 entries).  n_global = global batch size.
+ * dx_sum (nullable, C floats): sum of dx over (n, pixels) per channel in closed form - the gradient
+ * of a per-channel bias added before the normalisation (the conv bias of a ConvSnRelu block).
+ * accumulate: bit 0 - add to dmean_weight / dvar_weight instead of overwriting them; bit 1 - the same for dx_sum. */
 int snws_sn_bwd_mix_b(const float* ctx, float* ctxb, const float* packb, const float* mean_weight,
                       const float* var_weight, const float* running_mean, const float* running_var,
                       float* dmean_weight, float* dvar_weight, float* dx_sum, int N, int64_t HW, int C,
-                      float n_global, int training, int using_bn, void* stream);
+                      float n_global, int training, int using_bn, int accumulate, void* stream);
 /* Pass 2: dx = A*dy' + B*x + K. */
 int snws_sn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask, int64_t ldy,
                       void* dx, int64_t lddx, int dtype, const float* ctx, const float* ctxb, const float* beta,

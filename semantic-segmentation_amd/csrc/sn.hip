@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512) void sn_bwd_mix_a1_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void sn_bwd_mix_a2_kernel(float* __restrict__ ctxb, float* __restrict__ packb,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
-                                                            int C) {
+                                                            int C, int accumulate) {
   __shared__ double scratch[16];
   const CtxbOff ob = ctxb_off(N, C);
   if ((int)blockIdx.x < N) {
@@ -500,8 +500,8 @@ __global__ __launch_bounds__(256) void sn_bwd_mix_a2_kernel(float* __restrict__ 
       }
       packb[c] = (float)s1;
       packb[C + c] = (float)s2;
-      dgamma[c] = (float)sq;
-      dbeta[c] = (float)sp;
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sq;
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sp;
     }
   }
 }
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restr
                                                             const float* __restrict__ mw, const float* __restrict__ vw,
                                                             float* __restrict__ dmw, float* __restrict__ dvw,
                                                             float* __restrict__ dxsum, int N, int64_t HW, int C,
-                                                            float Ng, int training, int using_bn) {
+                                                            float Ng, int training, int using_bn, int accumulate) {
   const CtxOff o = ctx_off(N, C);
   const CtxbOff ob = ctxb_off(N, C);
   const int K = using_bn ? 3 : 2;
@@ -585,15 +585,15 @@ __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restr
     for (int c = threadIdx.x; c < C; c += 1024) {
       double s = 0;
       for (int n = 0; n < N; ++n) s += (double)ctxb[ob.dm + (int64_t)n * C + c];
-      dxsum[c] = (float)s;
+      dxsum[c] = ((accumulate & 2) ? dxsum[c] : 0.f) + (float)s;
     }
   }
   if (threadIdx.x == 0) {
     double sa = 0, sb = 0;
     for (int k = 0; k < K; ++k) { sa += a[k] * da[k]; sb += b[k] * db[k]; }
     for (int k = 0; k < K; ++k) {
-      dmw[k] = (float)(a[k] * (da[k] - sa));
-      dvw[k] = (float)(b[k] * (db[k] - sb));
+      dmw[k] = ((accumulate & 1) ? dmw[k] : 0.f) + (float)(a[k] * (da[k] - sa));
+      dvw[k] = ((accumulate & 1) ? dvw[k] : 0.f) + (float)(b[k] * (db[k] - sb));
     }
   }
 }
@@ -846,13 +846,14 @@ extern "C" int snws_sn_bwd_reduce(const void* dy, int64_t lddy, const void* x, i
 }
 
 extern "C" int snws_sn_bwd_mix_a(const float* part, int T, const float* ctx, const float* gamma, float* ctxb,
-                                 float* packb, float* dgamma, float* dbeta, int N, int C, void* stream) {
+                                 float* packb, float* dgamma, float* dbeta, int N, int C, int accumulate,
+                                 void* stream) {
   SNWS_CHECK_ARG(part && ctx && gamma && ctxb && packb && dgamma && dbeta, "snws_sn_bwd_mix_a: NULL pointer");
   SNWS_CHECK_ARG(N >= 1 && C >= 1 && T >= 1, "snws_sn_bwd_mix_a: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   sn_bwd_mix_a1_kernel<<<dim3(cdiv(C, 64), N), 512, 0, st>>>(part, T, ctx, gamma, ctxb, N, C);
   SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_a(1)");
-  sn_bwd_mix_a2_kernel<<<N + cdiv(C, 256), 256, 0, st>>>(ctxb, packb, dgamma, dbeta, N, C);
+  sn_bwd_mix_a2_kernel<<<N + cdiv(C, 256), 256, 0, st>>>(ctxb, packb, dgamma, dbeta, N, C, accumulate);
   SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_a(2)");
   return SNWS_OK;
 }
@@ -860,14 +861,14 @@ extern "C" int snws_sn_bwd_mix_a(const float* part, int T, const float* ctx, con
 extern "C" int snws_sn_bwd_mix_b(const float* ctx, float* ctxb, const float* packb, const float* mean_weight,
                                  const float* var_weight, const float* running_mean, const float* running_var,
                                  float* dmean_weight, float* dvar_weight, float* dx_sum, int N, int64_t HW, int C,
-                                 float n_global, int training, int using_bn, void* stream) {
+                                 float n_global, int training, int using_bn, int accumulate, void* stream) {
   (void)running_mean;
   (void)running_var;
   SNWS_CHECK_ARG(ctx && ctxb && packb && mean_weight && var_weight && dmean_weight && dvar_weight,
                  "snws_sn_bwd_mix_b: NULL pointer");
   SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1 && n_global >= 1.f, "snws_sn_bwd_mix_b: bad sizes");
   sn_bwd_mix_b_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ctx, ctxb, packb, mean_weight, var_weight, dmean_weight,
-                                                         dvar_weight, dx_sum, N, HW, C, n_global, training, using_bn);
+                                                         dvar_weight, dx_sum, N, HW, C, n_global, training, using_bn, accumulate);
   SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_b");
   return SNWS_OK;
 }

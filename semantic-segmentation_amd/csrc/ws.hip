@@ -58,7 +58,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restr
 
 __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restrict__ w, const float* __restrict__ g,
                                                             int64_t ldg, float* __restrict__ dw, int O, int I, int kh,
-                                                            int kw) {
+                                                            int kw, int accumulate) {
   __shared__ double scratch[16];
   const int o = blockIdx.x;
   const int taps = kh * kw, n = I * taps;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restr
 #pragma unroll
   for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
-    if (i < n) dw[(int64_t)o * n + i] = gg[k] - tm;
+    if (i < n) dw[(int64_t)o * n + i] = (accumulate ? dw[(int64_t)o * n + i] : 0.f) + (gg[k] - tm);
   }
 }
 
@@ -141,13 +141,13 @@ extern "C" int snws_conv_pack(const float* w, int O, int I, int kh, int kw, floa
 }
 
 extern "C" int snws_ws_bwd(const float* w, const float* g_ohwi, int64_t ldg, float* dw, int O, int I, int kh, int kw,
-                           void* stream) {
+                           int accumulate, void* stream) {
   SNWS_CHECK_ARG(w && g_ohwi && dw, "snws_ws_bwd: NULL pointer");
   SNWS_CHECK_ARG(O >= 1 && I >= 1 && kh >= 1 && kw >= 1 && ldg >= I, "snws_ws_bwd: bad shape");
   const int64_t n = (int64_t)I * kh * kw;
   SNWS_CHECK_ARG(n >= 2, "snws_ws_bwd: fan-in %lld < 2", (long long)n);
   if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_ws_bwd: fan-in %lld too large", (long long)n);
-  ws_bwd_kernel<<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, g_ohwi, ldg, dw, O, I, kh, kw);
+  ws_bwd_kernel<<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, g_ohwi, ldg, dw, O, I, kh, kw, accumulate);
   SNWS_LAUNCH_CHECK("snws_ws_bwd");
   return SNWS_OK;
 }

@@ -34,7 +34,7 @@ _SIGNATURES = {
     "snws_confusion_hist_argmax": (c_int, [P, c_int, P, c_int, c_int64, c_int64, c_int, P, P]),
     "snws_ws_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "snws_conv_pack": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P]),
-    "snws_ws_bwd": (c_int, [P, P, c_int64, P, c_int, c_int, c_int, c_int, P]),
+    "snws_ws_bwd": (c_int, [P, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_conv_pack_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "snws_conv_out_size": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "snws_conv_direct_fwd": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P]),
@@ -55,8 +55,8 @@ _SIGNATURES = {
     "snws_sn_apply": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, c_int, c_int64, c_int, c_int, P]),
     "snws_sn_bwd_reduce": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64, c_int, c_int,
                                    P, P]),
-    "snws_sn_bwd_mix_a": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, P]),
-    "snws_sn_bwd_mix_b": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_float, c_int, c_int, P]),
+    "snws_sn_bwd_mix_a": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "snws_sn_bwd_mix_b": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_float, c_int, c_int, c_int, P]),
     "snws_sn_bwd_apply": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64,
                                   c_int, c_int, P]),
     "snws_upconv_fwd": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

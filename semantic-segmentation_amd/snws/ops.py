@@ -53,7 +53,7 @@ def grad_key(param):
     return None if param is None else param.data_ptr()
 
 
-def grad_out(key, shape, device, zero=False):
+def grad_out(key, shape, device, zero=False, acc_ok=False):
     """Where a backward kernel should write d(loss)/d(parameter `key` = grad_key(param)): the parameter's slot in
     the flat gradient buffer when one is registered and still unused in this step, else a new float32 tensor of
     `shape` (zero-filled on request; a slot always is)."""
@@ -65,10 +65,24 @@ def grad_out(key, shape, device, zero=False):
         sink[3][0] = True
         flat, off, n = sink[:3]
         return flat[off:off + n].view(shape)
-    t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=device)
     if sink is not None and sink[3][0] and sink[2] == _numel(shape):
-        _FOLD[id(t)] = (t, sink)        # a further use of the parameter in this step: grad_fold adds it into the slot
-    return t
+        # a further use of the parameter in this step
+        if acc_ok:          # the kernel can add: hand it the slot itself; grad_fold then returns None to autograd
+            flat, off, n = sink[:3]
+            t = flat[off:off + n].view(shape)
+            _FOLD[id(t)] = (t, None)
+            return t
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=device)
+        _FOLD[id(t)] = (t, sink)        # grad_fold adds it into the slot
+        return t
+    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=device)
+
+
+def grad_accumulates(t):
+    """True when t (from grad_out(..., acc_ok=True)) is a slot that already holds this step's earlier gradient: the
+    kernel must add to it."""
+    e = _FOLD.get(id(t))
+    return e is not None and e[0] is t and e[1] is None
 
 
 _FOLD = {}
@@ -84,8 +98,9 @@ def grad_fold(t):
     entry = _FOLD.pop(id(t), None)
     if entry is None or entry[0] is not t:
         return t
-    flat, off, n = entry[1][:3]
-    flat[off:off + n].view(t.shape).add_(t)
+    if entry[1] is not None:
+        flat, off, n = entry[1][:3]
+        flat[off:off + n].view(t.shape).add_(t)
     return None
 
 
@@ -352,7 +367,7 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=N
     if need_dw or need_db:
         done = False
         if need_db:
-            db = grad_out(bias_key, (cfg.O,), dev, zero=True)
+            db = grad_out(bias_key, (cfg.O,), dev, zero=True, acc_ok=True)    # the wgrad kernels add to it
         if used_mfma and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
             g = torch.zeros((cfg.O, cfg.kh, cfg.kw, c_run), dtype=torch.float32, device=dev)
             d = cfg.desc(N, H, W, c_run, ldx, lddy)
@@ -366,15 +381,21 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=N
         if not done:
             g = torch.empty((cfg.O, cfg.kh, cfg.kw, cfg.Ig), dtype=torch.float32, device=dev)
             d = cfg.desc(N, H, W, C, ldx, lddy)
-            L.call("snws_conv_direct_wgrad", ctypes.byref(d), dt, _ptr(xs), _ptr(dys), _ptr(g), _ptr(db), _stream())
+            if db is not None and grad_accumulates(db):     # the direct kernel overwrites its bias gradient
+                db_once = torch.empty_like(db)
+                L.call("snws_conv_direct_wgrad", ctypes.byref(d), dt, _ptr(xs), _ptr(dys), _ptr(g), _ptr(db_once), _stream())
+                db.add_(db_once)
+            else:
+                L.call("snws_conv_direct_wgrad", ctypes.byref(d), dt, _ptr(xs), _ptr(dys), _ptr(g), _ptr(db), _stream())
             ldg = cfg.Ig
         if need_dw and not prep.standardize:
             dw = g[..., :cfg.Ig].permute(0, 3, 1, 2).contiguous()
         elif need_dw:
             w32 = weight.detach()
             w32 = (w32 if w32.dtype == torch.float32 else w32.float()).contiguous()
-            dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), dev)
-            L.call("snws_ws_bwd", _ptr(w32), _ptr(g), ldg, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
+            dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), dev, acc_ok=True)
+            L.call("snws_ws_bwd", _ptr(w32), _ptr(g), ldg, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw,
+                   int(grad_accumulates(dw)), _stream())
     return dx, grad_fold(dw), grad_fold(db)
 
 
@@ -522,18 +543,24 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None):
                 int(s["relu"]), _ptr(part), st)
     ctxb = torch.empty(lib.snws_sn_ctxb_floats(N, C), dtype=torch.float32, device=dev)
     packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
-    dgamma = grad_out(grad_key(s["gamma"]), (C,), dev)
-    dbeta = grad_out(grad_key(s["beta"]), (C,), dev)
+    dgamma = grad_out(grad_key(s["gamma"]), (C,), dev, acc_ok=True)
+    dbeta = grad_out(grad_key(s["beta"]), (C,), dev, acc_ok=True)
+    acc_a = grad_accumulates(dgamma) and grad_accumulates(dbeta)
+    if not acc_a and (grad_accumulates(dgamma) or grad_accumulates(dbeta)):
+        raise RuntimeError("SwitchNorm weight and bias must be used together")
     L.call("snws_sn_bwd_mix_a", _ptr(part), T, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(ctxb), _ptr(packb), _ptr(dgamma),
-           _ptr(dbeta), N, C, st)
+           _ptr(dbeta), N, C, int(acc_a), st)
     if s["synced"]:
         _allreduce_sum(packb, s["group"])
     K = s["mw"].numel()
-    dmw = grad_out(grad_key(s["mw"]), (K,), dev)
-    dvw = grad_out(grad_key(s["vw"]), (K,), dev)
-    dxsum = grad_out(dx_sum_key, (C,), dev) if want_dx_sum else None
+    dmw = grad_out(grad_key(s["mw"]), (K,), dev, acc_ok=True)
+    dvw = grad_out(grad_key(s["vw"]), (K,), dev, acc_ok=True)
+    dxsum = grad_out(dx_sum_key, (C,), dev, acc_ok=True) if want_dx_sum else None
+    if grad_accumulates(dmw) != grad_accumulates(dvw):
+        raise RuntimeError("SwitchNorm mean_weight and var_weight must be used together")
+    acc_b = int(grad_accumulates(dmw)) | (2 if dxsum is not None and grad_accumulates(dxsum) else 0)
     L.call("snws_sn_bwd_mix_b", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), _ptr(s["mw"]), _ptr(s["vw"]), None, None,
-           _ptr(dmw), _ptr(dvw), _ptr(dxsum), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), st)
+           _ptr(dmw), _ptr(dvw), _ptr(dxsum), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), acc_b, st)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
     _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]),
             s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C,
@@ -805,8 +832,9 @@ class TapConvFn(torch.autograd.Function):
         if dwre is not None:
             g = dwre.view(cfg.kh, cfg.kw, cfg.O, cfg.Ig).permute(2, 0, 1, 3).contiguous()
             w32 = _f32c(weight)
-            dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), g.device)
-            L.call("snws_ws_bwd", _ptr(w32), _ptr(g), cfg.Ig, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
+            dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), g.device, acc_ok=True)
+            L.call("snws_ws_bwd", _ptr(w32), _ptr(g), cfg.Ig, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw,
+                   int(grad_accumulates(dw)), _stream())
             dw = grad_fold(dw)
             if dw is not None:
                 dw = dw.to(weight.dtype)

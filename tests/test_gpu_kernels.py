@@ -176,9 +176,14 @@ def test_ws_fwd_bwd_golden():
         from snws import _lib as L
         import ctypes
         L.call("snws_ws_bwd", ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(g_ohwi.data_ptr()), w.shape[1],
-               ctypes.c_void_p(dw.data_ptr()), w.shape[0], w.shape[1], w.shape[2], w.shape[3], None)
+               ctypes.c_void_p(dw.data_ptr()), w.shape[0], w.shape[1], w.shape[2], w.shape[3], 0, None)
         torch.cuda.synchronize()
         assert relerr(dw, want) < 1e-4
+        # accumulate flag: a second call adds the same gradient
+        L.call("snws_ws_bwd", ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(g_ohwi.data_ptr()), w.shape[1],
+               ctypes.c_void_p(dw.data_ptr()), w.shape[0], w.shape[1], w.shape[2], w.shape[3], 1, None)
+        torch.cuda.synchronize()
+        assert relerr(dw, 2 * want) < 1e-4
 
 
 # ================================================================== direct convolution (exact f32 tier)
