@@ -29,7 +29,7 @@ class Conv2dws(nn.Conv2d):
         key = ops.filter_cache_key(w, want_mfma)
         if self._prep is None or key is None or self._prep_key != key:
             cfg = ops.ConvCfg(w.shape, self.stride, self.padding, self.dilation, self.groups)
-            self._prep = ops.PreparedWeight(w, cfg, want_mfma)
+            self._prep = ops.PreparedWeight(w, cfg, want_mfma, reuse=self._prep if ops.CACHE_FILTERS else None)
             self._prep_key = key
         return self._prep
 

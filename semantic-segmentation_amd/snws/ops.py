@@ -200,7 +200,9 @@ class ConvCfg:
 class PreparedWeight:
     """Standardized filter in the layouts the kernels read, valid for one version of the master weight."""
 
-    def __init__(self, weight, cfg, want_mfma, standardize=True):
+    def __init__(self, weight, cfg, want_mfma, standardize=True, reuse=None):
+        """reuse: the PreparedWeight of the previous weight version, whose buffers are overwritten in place (only a
+        driver that owns the step structure, i.e. CACHE_FILTERS, may pass it: no graph may still need the old images)."""
         require_gpu(weight, "Conv2dws")
         self.standardize = standardize
         w = weight.detach()
@@ -209,9 +211,14 @@ class PreparedWeight:
         w = w.contiguous()
         dev = w.device
         self.cfg = cfg
-        self.ohwi = torch.empty((cfg.O, cfg.kh, cfg.kw, cfg.Ig), dtype=torch.float32, device=dev)
         self.pack_fwd = self.pack_dgrad = None
-        if want_mfma:
+        if reuse is not None and reuse.ohwi.device == dev and tuple(reuse.ohwi.shape) == (cfg.O, cfg.kh, cfg.kw, cfg.Ig) and \
+                (reuse.pack_fwd is not None) == bool(want_mfma):
+            self.ohwi, self.pack_fwd, self.pack_dgrad = reuse.ohwi, reuse.pack_fwd, reuse.pack_dgrad   # padding stays zero
+        else:
+            self.ohwi = torch.empty((cfg.O, cfg.kh, cfg.kw, cfg.Ig), dtype=torch.float32, device=dev)
+            reuse = None
+        if want_mfma and reuse is None:
             nbytes = L.lib().snws_conv_pack_bytes(cfg.I, cfg.O, cfg.kh, cfg.kw)
             self.pack_fwd = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=dev)
             nbytes = L.lib().snws_conv_pack_bytes(cfg.O, cfg.I, cfg.kh, cfg.kw)
