@@ -12,7 +12,9 @@ namespace {
 constexpr int WS_THREADS = 256;
 constexpr int WS_MAX_PER_THREAD = 64;  // fan-in up to 16384
 
-template <bool STANDARDIZE>
+// PT = elements of the fan-in per thread (4, 16 or 64): the loops are fully unrolled over it, so a small fan-in must
+// not pay for 64 predicated iterations.
+template <bool STANDARDIZE, int PT>
 __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restrict__ w, int O, int I, int kh, int kw,
                                                             float* __restrict__ what_oihw,
                                                             float* __restrict__ what_ohwi, bf16_t* __restrict__ pk_fwd,
@@ -21,10 +23,10 @@ __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restr
   const int o = blockIdx.x;
   const int taps = kh * kw, n = I * taps;
   const float* wo = w + (int64_t)o * n;
-  float v[WS_MAX_PER_THREAD];
+  float v[PT];
   double s = 0;
 #pragma unroll
-  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+  for (int k = 0; k < PT; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
     v[k] = i < n ? wo[i] : 0.f;
     s += v[k];
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restr
     const float mu = (float)(block_sum(s, scratch) / n);
     double ss = 0;
 #pragma unroll
-    for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+    for (int k = 0; k < PT; ++k) {
       const int i = threadIdx.x + k * WS_THREADS;
       v[k] = i < n ? v[k] - mu : 0.f;
       ss += (double)v[k] * v[k];
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restr
   const PackGeom gf = pack_geom(I, O, taps);   // forward image: contraction over input channels
   const PackGeom gd = pack_geom(O, I, taps);   // dgrad image: contraction over output channels
 #pragma unroll
-  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+  for (int k = 0; k < PT; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
     if (i >= n) break;
     const float h = STANDARDIZE ? v[k] / sd : v[k];
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restr
   }
 }
 
+template <int PT>
 __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restrict__ w, const float* __restrict__ g,
                                                             int64_t ldg, float* __restrict__ dw, int O, int I, int kh,
                                                             int kw, int accumulate) {
@@ -63,10 +66,10 @@ __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restr
   const int o = blockIdx.x;
   const int taps = kh * kw, n = I * taps;
   const float* wo = w + (int64_t)o * n;
-  float c[WS_MAX_PER_THREAD], gg[WS_MAX_PER_THREAD];
+  float c[PT], gg[PT];
   double s = 0;
 #pragma unroll
-  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+  for (int k = 0; k < PT; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
     c[k] = i < n ? wo[i] : 0.f;
     s += c[k];
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restr
   const float mu = (float)(block_sum(s, scratch) / n);
   double ss = 0, gc = 0;
 #pragma unroll
-  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+  for (int k = 0; k < PT; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
     if (i < n) {
       const int ci = i / taps, tap = i % taps;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restr
   const double k2 = gc / (d * d * (n - 1) * sdev);
   double ts = 0;
 #pragma unroll
-  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+  for (int k = 0; k < PT; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
     const double t = i < n ? (double)gg[k] / d - k2 * c[k] : 0.0;
     gg[k] = (float)t;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restr
   }
   const float tm = (float)(block_sum(ts, scratch) / n);
 #pragma unroll
-  for (int k = 0; k < WS_MAX_PER_THREAD; ++k) {
+  for (int k = 0; k < PT; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
     if (i < n) dw[(int64_t)o * n + i] = (accumulate ? dw[(int64_t)o * n + i] : 0.f) + (gg[k] - tm);
   }
@@ -122,8 +125,9 @@ extern "C" int snws_ws_fwd(const float* w, int O, int I, int kh, int kw, float* 
   const int64_t n = (int64_t)I * kh * kw;
   SNWS_CHECK_ARG(n >= 2, "snws_ws_fwd: fan-in %lld < 2 has no unbiased std", (long long)n);
   if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_ws_fwd: fan-in %lld > %d", (long long)n, WS_THREADS * WS_MAX_PER_THREAD);
-  ws_fwd_kernel<true><<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, O, I, kh, kw, what_oihw, what_ohwi,
-                                                               (bf16_t*)pack_fwd, (bf16_t*)pack_dgrad);
+#define WS_FWD(PT) ws_fwd_kernel<true, PT><<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, O, I, kh, kw, what_oihw, what_ohwi, (bf16_t*)pack_fwd, (bf16_t*)pack_dgrad)
+  if (n <= 4 * WS_THREADS) WS_FWD(4); else if (n <= 16 * WS_THREADS) WS_FWD(16); else WS_FWD(64);
+#undef WS_FWD
   SNWS_LAUNCH_CHECK("snws_ws_fwd");
   return SNWS_OK;
 }
@@ -134,8 +138,9 @@ extern "C" int snws_conv_pack(const float* w, int O, int I, int kh, int kw, floa
   SNWS_CHECK_ARG(O >= 1 && I >= 1 && kh >= 1 && kw >= 1, "snws_conv_pack: bad shape (%d,%d,%d,%d)", O, I, kh, kw);
   const int64_t n = (int64_t)I * kh * kw;
   if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_conv_pack: fan-in %lld > %d", (long long)n, WS_THREADS * WS_MAX_PER_THREAD);
-  ws_fwd_kernel<false><<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, O, I, kh, kw, nullptr, w_ohwi, (bf16_t*)pack_fwd,
-                                                                (bf16_t*)pack_dgrad);
+#define WS_PACK(PT) ws_fwd_kernel<false, PT><<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, O, I, kh, kw, nullptr, w_ohwi, (bf16_t*)pack_fwd, (bf16_t*)pack_dgrad)
+  if (n <= 4 * WS_THREADS) WS_PACK(4); else if (n <= 16 * WS_THREADS) WS_PACK(16); else WS_PACK(64);
+#undef WS_PACK
   SNWS_LAUNCH_CHECK("snws_conv_pack");
   return SNWS_OK;
 }
@@ -147,7 +152,9 @@ extern "C" int snws_ws_bwd(const float* w, const float* g_ohwi, int64_t ldg, flo
   const int64_t n = (int64_t)I * kh * kw;
   SNWS_CHECK_ARG(n >= 2, "snws_ws_bwd: fan-in %lld < 2", (long long)n);
   if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_ws_bwd: fan-in %lld too large", (long long)n);
-  ws_bwd_kernel<<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, g_ohwi, ldg, dw, O, I, kh, kw, accumulate);
+#define WS_BWD(PT) ws_bwd_kernel<PT><<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, g_ohwi, ldg, dw, O, I, kh, kw, accumulate)
+  if (n <= 4 * WS_THREADS) WS_BWD(4); else if (n <= 16 * WS_THREADS) WS_BWD(16); else WS_BWD(64);
+#undef WS_BWD
   SNWS_LAUNCH_CHECK("snws_ws_bwd");
   return SNWS_OK;
 }
