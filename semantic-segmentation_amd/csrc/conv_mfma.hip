@@ -847,6 +847,150 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1_kernel(WgradArgs a) {
   if (want_bias && tid < 64 && cot * 64 + tid < a.Cout) atomicAdd(a.dbias + cot * 64 + tid, bias_sum);
 }
 
+// 1x1 wgrad for wide layers (both channel counts above 64): a 128x128 (out, in) channel tile per workgroup, one 64x64
+// quadrant per wave, over tiles of 128 CONSECUTIVE pixels (a 1x1 convolution has no spatial structure, so the N*H*W
+// pixels are one linear axis).  Against the 64-wide kernel every staged byte feeds twice the matrix work and the
+// operands are re-read half as often.  LDS image per operand: [128 px][128 ch] bf16 (256 B per pixel, 16 chunks of
+// 16 B); chunk c of pixel p sits in slot c ^ ((p & 3) << 2), so the four pixel rows of a transposing read land in
+// four different 64-byte bank windows.
+struct Wgrad1wArgs {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* dw;
+  float* dbias;
+  int64_t P;                 // N*H*W pixels
+  int Cin, Cout;
+  int64_t ldx, lddy;
+  int coTiles, ciTiles, tilesPerSplit, ntiles;
+};
+
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad1w_kernel(Wgrad1wArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* dy_lds = smem;              // 32 KB
+  unsigned char* x_lds = smem + 32768;       // 32 KB
+  float* b_lds = reinterpret_cast<float*>(smem + 65536);   // [4 waves][128 channels]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int npairs = a.coTiles * a.ciTiles;
+  const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = bid % npairs, split = bid / npairs;
+  const int cot = pair % a.coTiles, cit = pair / a.coTiles;
+  const int t_begin = split * a.tilesPerSplit;
+  const int t_end = t_begin + a.tilesPerSplit < a.ntiles ? t_begin + a.tilesPerSplit : a.ntiles;
+  const bool want_bias = BIAS && cit == 0;
+  const int co_q = wave & 1, ci_q = wave >> 1;      // this wave's 64x64 quadrant
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+  if (want_bias) {
+    b_lds[tid] = 0.f;
+    b_lds[tid + 256] = 0.f;
+  }
+
+  // transposing-read geometry: lane -> pixel kb + gq (+4 for the second half) of a 16-pixel k-step, channels rb + 4gp ..
+  const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
+  const int rb = (grp & 1) * 16, kb = (grp >> 1) * 8;
+  const int cb0 = kb + gq;                          // (cb0 & 3) == gq, also for cb0 + 4
+  const unsigned char *abase[2], *bbase[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int cha = co_q * 64 + h * 32 + rb + 4 * gp, chb = ci_q * 64 + h * 32 + rb + 4 * gp;
+    abase[h] = dy_lds + cb0 * 256 + (((cha >> 3) ^ (gq << 2)) * 16) + (cha & 7) * 2;
+    bbase[h] = x_lds + cb0 * 256 + (((chb >> 3) ^ (gq << 2)) * 16) + (chb & 7) * 2;
+  }
+  // staging: a 1 KiB piece = 4 pixels x 16 chunks; lane = (pixel q, slot); slot holds chunk slot ^ ((q & 3) << 2)
+  const int st_q = lane >> 4, st_chunk = (lane & 15) ^ (st_q << 2);
+  const bool st_dy_ok = cot * 128 + st_chunk * 8 < a.Cout, st_x_ok = cit * 128 + st_chunk * 8 < a.Cin;
+  const bf16_t* dyc = a.dy + cot * 128 + st_chunk * 8;
+  const bf16_t* xc = a.x + cit * 128 + st_chunk * 8;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int64_t p0 = (int64_t)t * 128;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {            // piece wave + 4j: pixels 4*(wave + 4j) .. +3
+      const int64_t p = p0 + 4 * (wave + 4 * j) + st_q;
+      const bool in = p < a.P;
+      const void* sd = (in && st_dy_ok) ? (const void*)(dyc + p * a.lddy) : (const void*)snws_zero_page;
+      const void* sx = (in && st_x_ok) ? (const void*)(xc + p * a.ldx) : (const void*)snws_zero_page;
+      glds16(sd, dy_lds + (wave + 4 * j) * 1024);
+      glds16(sx, x_lds + (wave + 4 * j) * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (want_bias) {  // bias gradient: column sums of the dy tile; thread = (16-byte slot, group of 8 pixels)
+      const int slot = tid & 15, pg = tid >> 4;
+      float bs[4][8];                      // by pixel class pix & 3: slot holds chunk slot ^ (class << 2)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[c][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f[8];
+        Vec<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(dy_lds + (pg * 8 + j) * 256 + slot * 16), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[j & 3][e] += f[e];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = bs[c][e];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (lane < 16) b_lds[wave * 128 + (slot ^ (c << 2)) * 8 + e] += v;
+        }
+    }
+
+    bf16x8 af[2][2], bf[2][2];
+    auto load_step = [&](int s_) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        af[s_ & 1][h] = tr_frag(abase[h] + s_ * 4096, abase[h] + s_ * 4096 + 1024);
+        bf[s_ & 1][h] = tr_frag(bbase[h] + s_ * 4096, bbase[h] + s_ * 4096 + 1024);
+      }
+    };
+    load_step(0);
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+      if (s_ + 1 < 8) load_step(s_ + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s_ & 1][i], bf[s_ & 1][h], acc[i][h], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ci = cit * 128 + ci_q * 64 + h * 32 + (lane & 31);
+      const bool ci_ok = ci < a.Cin;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * 128 + co_q * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ci_ok && co < a.Cout) atomicAdd(a.dw + (int64_t)co * a.Cin + ci, acc[i][h][r]);
+      }
+    }
+  }
+  if (want_bias && tid < 128 && cot * 128 + tid < a.Cout)   // the loop's last barrier ordered every wave's partials
+    atomicAdd(a.dbias + cot * 128 + tid, b_lds[tid] + b_lds[tid + 128] + b_lds[tid + 256] + b_lds[tid + 384]);
+}
+
 // 3x3 wgrad over 64-wide in-channel tiles.  The generic kernel above reads one B fragment from LDS per MFMA, which
 // asks the LDS for its full 128 B/clk at the matrix pipe's peak rate.  Here a wave owns ALL 64 out channels (two A
 // fragments) x one 32-wide in-channel half x a group of 5 or 4 taps, so every B fragment feeds two MFMAs (7
@@ -1216,6 +1360,24 @@ int launch_wgrad1(const WgradArgs& a, unsigned grid, hipStream_t st) {
 }
 
 template <bool BIAS>
+int launch_wgrad1w(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
+  constexpr int LDS = 65536 + 4 * 128 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1w_kernel<BIAS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  conv_wgrad1w_kernel<BIAS><<<grid, 256, LDS, st>>>(a);
+  SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
+  return SNWS_OK;
+}
+
+template <bool BIAS>
 int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<64, 9>;
   static bool attr_set = false;
@@ -1296,6 +1458,26 @@ extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, cons
   if (c64) {
     static const bool generic1 = getenv("SNWS_WGRAD_GENERIC") != nullptr;
     if (generic1) return launch_wgrad<64, 1>(a, grid, st);
+    static const bool narrow1 = getenv("SNWS_WGRAD1_NARROW") != nullptr;    // A/B switch: the 64-wide 1x1 kernel
+    // the wide kernel pays when its 128-wide tiles are mostly full (measured: 512->256 @512^2 2x the narrow kernel;
+    // 320->576, whose tiles are 25 % padding, 0.85x)
+    const int64_t padded = (int64_t)cdiv(d->C_in, 128) * 128 * cdiv(d->C_out, 128) * 128;
+    if (!narrow1 && d->C_in > 64 && d->C_out > 64 && padded * 5 <= (int64_t)d->C_in * d->C_out * 6) {
+      Wgrad1wArgs w;
+      w.x = a.x; w.dy = a.dy; w.dw = a.dw; w.dbias = a.dbias;
+      w.P = (int64_t)d->N * d->H * d->W; w.Cin = d->C_in; w.Cout = d->C_out; w.ldx = d->ldx; w.lddy = d->ldy;
+      w.coTiles = cdiv(d->C_out, 128); w.ciTiles = cdiv(d->C_in, 128);
+      const int64_t nt = (w.P + 127) / 128;
+      SNWS_CHECK_ARG(nt < (1ll << 31), "snws_conv_mfma_wgrad: too many pixels");
+      w.ntiles = (int)nt;
+      const int np = w.coTiles * w.ciTiles;
+      int sp = 512 / np;                       // one resident round of long workgroups (64 KB atomic flush each)
+      if (sp < 1) sp = 1;
+      if (sp > w.ntiles) sp = w.ntiles;
+      w.tilesPerSplit = cdiv(w.ntiles, sp);
+      sp = cdiv(w.ntiles, w.tilesPerSplit);
+      return dbias ? launch_wgrad1w<true>(w, (unsigned)(np * sp), st) : launch_wgrad1w<false>(w, (unsigned)(np * sp), st);
+    }
     return dbias ? launch_wgrad1<true>(a, grid, st) : launch_wgrad1<false>(a, grid, st);
   }
   return taps == 9 ? launch_wgrad<16, 9>(a, grid, st) : launch_wgrad<16, 1>(a, grid, st);

@@ -237,6 +237,8 @@ MFMA_CASES = [
     (1, 64, 64, 32, 64, 1),     # 1x1
     (2, 320, 144, 19, 37, 1),   # 1x1, channel tails in both tile directions, ragged pixel tiles
     (1, 1024, 576, 8, 8, 1),    # 1x1, many tile pairs, one pixel tile
+    (2, 128, 256, 9, 13, 1),    # 1x1 wide kernel, pixel count not a multiple of its 128-pixel tile
+    (1, 112, 248, 24, 40, 1),   # 1x1 wide kernel, channel tails in both tile directions
     (1, 32, 24, 8, 8, 3),       # C_out not a multiple of 64 (direct wgrad), tiny map
 ]
 
