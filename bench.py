@@ -214,7 +214,7 @@ def main():
                         "avg_launch_ms": tt / cnt * 1e3, "flops_per_launch": fl / cnt}
         summary = {}
         for tag, (cnt, work, tt) in sorted(kernels.items()):
-            if tag.startswith("conv"):
+            if tag.startswith(("conv", "gemm")):
                 summary[tag] = {"launches": cnt, "ms_per_step": tt / args.steps * 1e3, "TFLOP/s": work / tt / 1e12}
             else:
                 summary[tag] = {"launches": cnt, "ms_per_step": tt / args.steps * 1e3, "GB/s": work / tt / 1e9,

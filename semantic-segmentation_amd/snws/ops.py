@@ -124,7 +124,7 @@ def _numel(shape):
 # Off by default: measured +1.6 % images/s on the 512^2 benchmark, but kernels of the two streams then share the chip
 # and per-kernel event timings stop describing one kernel.
 WGRAD_STREAM = int(os.environ.get("SNWS_WGRAD_STREAM", "0"))     # 0 off, 1 the 3x3 layers, 2 also the 1x1 tap convs
-_SIDE = {}      # device index -> [stream, a join is queued for the running backward pass]
+_SIDE = {}      # device index -> [stream, work enqueued since the last join]
 
 
 def _has_sink(key, numel):
@@ -133,22 +133,23 @@ def _has_sink(key, numel):
 
 
 def _side_stream(dev):
-    """The device's side stream, or None outside a backward pass (nothing would join it)."""
+    """The device's side stream, or None outside a backward pass (nothing would join it).  Every use queues its own
+    end-of-backward join (a pass that raised never ran the earlier ones); only the first to run has work to do."""
     e = _SIDE.get(dev.index)
     if e is None:
         e = _SIDE[dev.index] = [torch.cuda.Stream(device=dev, priority=-1), False]
-    if not e[1]:
-        main = torch.cuda.current_stream(dev)
+    main = torch.cuda.current_stream(dev)
 
-        def join():
+    def join():
+        if e[1]:
             e[1] = False
             main.wait_stream(e[0])
             torch.cuda.current_stream(dev).wait_stream(e[0])
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(join)
-        except RuntimeError:
-            return None
-        e[1] = True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+    except RuntimeError:
+        return None
+    e[1] = True
     return e[0]
 
 
@@ -170,6 +171,18 @@ def _launch(tag, work, name, *args):
     e1.record()
     PROFILE.append((tag, work, e0, e1))
     return rc
+
+
+def _timed(tag, work, fn):
+    """fn() bracketed by events like _launch, for work that is not a libsnws call (the library GEMMs)."""
+    if PROFILE is None or (PROFILE_ONLY is not None and not tag.startswith(PROFILE_ONLY)):
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.append((tag, work, e0, e1))
+    return r
 
 
 def _ptr(t):
@@ -759,15 +772,56 @@ class Conv2dwsFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+GEMM_1X1 = os.environ.get("SNWS_CONV1X1_GEMM", "1") != "0"
+
+
+def _gemm_1x1_ok(x, cfg):
+    """Plain 1x1 convolutions wide enough (>= 128 channels both sides) that a 64-channel output tile would re-read
+    the pixels more than once."""
+    return GEMM_1X1 and cfg.kh == 1 and cfg.kw == 1 and x.dtype == torch.bfloat16 and x.is_cuda and \
+        cfg.I >= 128 and cfg.O >= 128 and cfg.I % 16 == 0 and cfg.O % 16 == 0
+
+
+class _PlainCfg:
+    """What _conv_backward_weights reads of a PreparedWeight, for a convolution that never built filter images."""
+    standardize = False
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+
 class PlainConvFn(torch.autograd.Function):
     """A plain (not standardized) convolution through the same kernels - the nn.Conv2d classification head."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         cfg = ConvCfg(weight.shape, 1, (weight.shape[2] - 1) // 2, 1, 1)
+        ctx.in_segs = input_segments(x)
+        ctx.gemm_w = None
+        if ctx.in_segs is None and _gemm_1x1_ok(x, cfg):
+            # a wide plain 1x1 convolution of a dense NHWC tensor IS a plain GEMM [pixels x C_in] x [C_in x C_out]:
+            # the vendor GEMM runs it (and its dgrad) 1.4-2x faster than the 64-channel-tile conv kernel, which re-stages
+            # the pixels once per 64 output channels; the weight gradient stays on snws_conv_mfma_wgrad (f32 result)
+            N, C, H, W = x.shape
+            xs, ldx = as_nhwc(x)
+            if ldx % 8 == 0 and xs.data_ptr() % 16 == 0:
+                wb = weight.detach().reshape(cfg.O, C).to(torch.bfloat16)
+                x2 = xs.permute(0, 2, 3, 1).reshape(N * H * W, C)
+                y = new_nhwc(N, cfg.O, H, W, x.dtype, x.device)
+                y2 = y.permute(0, 2, 3, 1).view(N * H * W, cfg.O)
+                flops = 2.0 * N * H * W * cfg.O * C
+                if bias is None:
+                    _timed("gemm_1x1_fwd", flops, lambda: torch.mm(x2, wb.t(), out=y2))
+                else:
+                    bb = bias.detach().to(torch.bfloat16)
+                    _timed("gemm_1x1_fwd", flops, lambda: torch.addmm(bb, x2, wb.t(), out=y2))
+                ctx.gemm_w = wb
+                ctx.prep = _PlainCfg(cfg)
+                ctx.saved, ctx.has_bias, ctx.bias_key = (xs, ldx, (N, C, H, W), True), bias is not None, grad_key(bias)
+                ctx.save_for_backward(weight)
+                return y
         prep = PreparedWeight(weight, cfg, x.dtype == torch.bfloat16, standardize=False)
         y, _, saved = conv_forward(x, prep, bias)
-        ctx.in_segs = input_segments(x)
         ctx.prep, ctx.saved, ctx.has_bias, ctx.bias_key = prep, saved, bias is not None, grad_key(bias)
         ctx.save_for_backward(weight)
         return y
@@ -776,6 +830,22 @@ class PlainConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.gemm_w is not None:
+            wb, (xs, ldx, (N, C, H, W), _) = ctx.gemm_w, ctx.saved
+            dys, lddy = as_nhwc(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16))
+            dx = dw = db = None
+            if nx:
+                dx = new_nhwc(N, C, H, W, dys.dtype, dys.device)
+                dy2 = dys.permute(0, 2, 3, 1).reshape(N * H * W, wb.shape[0])
+                _timed("gemm_1x1_dgrad", 2.0 * N * H * W * wb.shape[0] * C,
+                       lambda: torch.mm(dy2, wb, out=dx.permute(0, 2, 3, 1).view(N * H * W, C)))
+            if nw or nb:
+                if lddy % 8 or dys.data_ptr() % 16:
+                    dys = dys.contiguous(memory_format=torch.channels_last)
+                    lddy = dys.shape[1]
+                dw, db = _conv_backward_weights(dys, lddy, ctx.prep, ctx.saved, weight, nw, nb, ctx.bias_key)
+            ctx.saved = ctx.gemm_w = None
+            return dx, None if dw is None else dw.to(weight.dtype), db
         dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
         ctx.in_segs = None
         if dw is not None:

@@ -1329,3 +1329,53 @@ def test_weight_gradients_on_side_stream_match_single_stream():
         assert err < max(10 * noise, 1e-5), (err, noise)
     print("side-stream weight gradients: rel diff %.2e (run-to-run noise %.2e)" % (err, noise))
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,with_bias,sliced", [(256, 128, True, False), (512, 256, False, False),
+                                                       (128, 320, True, True)])
+def test_wide_plain_1x1_conv_gemm_route_matches_conv_kernel(cin, cout, with_bias, sliced):
+    """Plain 1x1 convolutions with >= 128 channels on both sides run forward and dgrad as a library GEMM over the NHWC
+    pixels; the result must equal the library's own MFMA conv kernel route (same bf16 operands, f32 accumulation)
+    within the bf16 bar, and the float64 product within 2e-2.  `sliced`: the input is a channel slice of a wider
+    NHWC buffer (pixel stride > C_in)."""
+    from snws import ops
+    torch.manual_seed(3)
+    N, H, W = 2, 24, 40
+    wide = torch.randn(N, H, W, cin + 64, device=DEV).to(torch.bfloat16)
+    x0 = (wide[..., 64:] if sliced else wide[..., :cin].contiguous()).permute(0, 3, 1, 2)
+    w0 = (torch.randn(cout, cin, 1, 1, device=DEV) / cin ** 0.5)
+    b0 = torch.randn(cout, device=DEV) if with_bias else None
+    dy = torch.randn(N, H, W, cout, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+    out = {}
+    prev = ops.GEMM_1X1
+    try:
+        for gemm in (True, False):
+            ops.GEMM_1X1 = gemm
+            x = x0.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) if not sliced else \
+                x0.detach().requires_grad_(True)
+            w = w0.clone().requires_grad_(True)
+            b = None if b0 is None else b0.clone().requires_grad_(True)
+            ops.PROFILE, tags = [], None
+            y = ops.PlainConvFn.apply(x, w, b)
+            y.backward(dy)
+            tags = {t[0] for t in ops.PROFILE}
+            ops.PROFILE = None
+            assert ("gemm_1x1_fwd" in tags and "gemm_1x1_dgrad" in tags) == gemm, tags
+            out[gemm] = (y.detach().float(), x.grad.float(), w.grad.float(), None if b is None else b.grad.float())
+    finally:
+        ops.GEMM_1X1 = prev
+        ops.PROFILE = None
+    xd, wd = x0.double(), w0.to(torch.bfloat16).double().view(cout, cin)
+    ref = torch.einsum("nchw,oc->nohw", xd, wd) + (0 if b0 is None else b0.double().view(1, -1, 1, 1))
+    refdx = torch.einsum("nohw,oc->nchw", dy.double(), wd)
+    refdw = torch.einsum("nohw,nchw->oc", dy.double(), xd).view(cout, cin, 1, 1)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    for gemm in (True, False):
+        assert rel(out[gemm][0], ref) < 2e-2 and rel(out[gemm][1], refdx) < 2e-2 and rel(out[gemm][2], refdw) < 1e-3
+    assert rel(out[True][0], out[False][0]) < 5e-3 and rel(out[True][1], out[False][1]) < 5e-3
+    assert rel(out[True][2], out[False][2]) < 1e-5
+    if with_bias:
+        assert rel(out[True][3], dy.double().sum((0, 2, 3))) < 1e-4 and rel(out[True][3], out[False][3]) < 1e-5
+
