@@ -520,38 +520,62 @@ __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restr
   softmax_k(vw, K, b);
   const bool bn_batch = using_bn && training;
   double da[3] = {0, 0, 0}, db[3] = {0, 0, 0};
-  const int64_t NC = (int64_t)N * C;
-  for (int64_t i = threadIdx.x; i < NC; i += 1024) {
-    const int n = (int)(i / C), c = (int)(i % C);
-    const float dm = ctxb[ob.dm + i], dv = ctxb[ob.dv + i];
-    const float mean_in = ctx[o.mean_in + i], var_in = ctx[o.var_in + i];
-    const float mean_ln = ctx[o.ln + 2 * n], var_ln = ctx[o.ln + 2 * n + 1];
-    da[0] += (double)dm * mean_in;
-    da[1] += (double)dm * mean_ln;
-    db[0] += (double)dv * var_in;
-    db[1] += (double)dv * var_ln;
-    const float dvar_ln = b[1] * ctxb[ob.lnb + 2 * n + 1];
-    const float dmean_ln = a[1] * ctxb[ob.lnb + 2 * n] - 2.f * mean_ln * dvar_ln;
-    float dtemp = dvar_ln / C;
-    float dmean_in = a[0] * dm + dmean_ln / C;
-    if (using_bn) {
-      const float mean_bn = ctx[o.bn + c], var_bn = ctx[o.bn + C + c];
-      da[2] += (double)dm * mean_bn;
-      db[2] += (double)dv * var_bn;
-      if (bn_batch) {
-        const float dvar_bn = b[2] * packb[C + c];
-        const float dmean_bn = a[2] * packb[c] - 2.f * mean_bn * dvar_bn;
-        dtemp += dvar_bn / Ng;
-        dmean_in += dmean_bn / Ng;
-      }
+  const int NC = N * C;      // the host checks N * C < 2^31
+  constexpr int U = 4;       // entries per thread per round: all their loads are issued before the first store
+  for (int i0 = threadIdx.x; i0 < NC; i0 += 1024 * U) {
+    float dm[U], dv[U], mean_in[U], var_in[U], mean_ln[U], var_ln[U], lnb0[U], lnb1[U], mean_bn[U], var_bn[U], pk0[U],
+        pk1[U], sc[U], Pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 1024;
+      const bool ok = i < NC;
+      const int ii = ok ? i : 0;
+      const int n = ii / C, c = ii - n * C;
+      dm[u] = ok ? ctxb[ob.dm + ii] : 0.f;
+      dv[u] = ok ? ctxb[ob.dv + ii] : 0.f;
+      mean_in[u] = ctx[o.mean_in + ii];
+      var_in[u] = ctx[o.var_in + ii];
+      mean_ln[u] = ctx[o.ln + 2 * n];
+      var_ln[u] = ctx[o.ln + 2 * n + 1];
+      lnb0[u] = ctxb[ob.lnb + 2 * n];
+      lnb1[u] = ctxb[ob.lnb + 2 * n + 1];
+      mean_bn[u] = using_bn ? ctx[o.bn + c] : 0.f;
+      var_bn[u] = using_bn ? ctx[o.bn + C + c] : 0.f;
+      pk0[u] = bn_batch ? packb[c] : 0.f;
+      pk1[u] = bn_batch ? packb[C + c] : 0.f;
+      sc[u] = ctx[o.scale + ii];
+      Pv[u] = ctxb[ob.P + ii];
     }
-    const float dvar_in = b[0] * dv + dtemp;
-    dmean_in += 2.f * mean_in * dtemp;
-    const float B = 2.f * dvar_in / (float)(HW - 1);
-    ctxb[ob.B + i] = B;
-    ctxb[ob.K + i] = dmean_in / (float)HW - B * mean_in;
-    // sum over the plane of dx = A*dy' + B*x + K is A*P + dmean_in; parked in the (now consumed) dm slot
-    ctxb[ob.dm + i] = ctx[o.scale + i] * ctxb[ob.P + i] + dmean_in;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 1024;
+      if (i >= NC) break;
+      da[0] += (double)dm[u] * mean_in[u];
+      da[1] += (double)dm[u] * mean_ln[u];
+      db[0] += (double)dv[u] * var_in[u];
+      db[1] += (double)dv[u] * var_ln[u];
+      const float dvar_ln = b[1] * lnb1[u];
+      const float dmean_ln = a[1] * lnb0[u] - 2.f * mean_ln[u] * dvar_ln;
+      float dtemp = dvar_ln / C;
+      float dmean_in = a[0] * dm[u] + dmean_ln / C;
+      if (using_bn) {
+        da[2] += (double)dm[u] * mean_bn[u];
+        db[2] += (double)dv[u] * var_bn[u];
+        if (bn_batch) {
+          const float dvar_bn = b[2] * pk1[u];
+          const float dmean_bn = a[2] * pk0[u] - 2.f * mean_bn[u] * dvar_bn;
+          dtemp += dvar_bn / Ng;
+          dmean_in += dmean_bn / Ng;
+        }
+      }
+      const float dvar_in = b[0] * dv[u] + dtemp;
+      dmean_in += 2.f * mean_in[u] * dtemp;
+      const float B = 2.f * dvar_in / (float)(HW - 1);
+      ctxb[ob.B + i] = B;
+      ctxb[ob.K + i] = dmean_in / (float)HW - B * mean_in[u];
+      // sum over the plane of dx = A*dy' + B*x + K is A*P + dmean_in; parked in the (now consumed) dm slot
+      ctxb[ob.dm + i] = sc[u] * Pv[u] + dmean_in;
+    }
   }
   {   // the six sums in one round trip through LDS
     __shared__ double red6[6][16];
@@ -866,7 +890,8 @@ extern "C" int snws_sn_bwd_mix_b(const float* ctx, float* ctxb, const float* pac
   (void)running_var;
   SNWS_CHECK_ARG(ctx && ctxb && packb && mean_weight && var_weight && dmean_weight && dvar_weight,
                  "snws_sn_bwd_mix_b: NULL pointer");
-  SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1 && n_global >= 1.f, "snws_sn_bwd_mix_b: bad sizes");
+  SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1 && n_global >= 1.f && (int64_t)N * C < (1ll << 31),
+                 "snws_sn_bwd_mix_b: bad sizes");
   sn_bwd_mix_b_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ctx, ctxb, packb, mean_weight, var_weight, dmean_weight,
                                                          dvar_weight, dx_sum, N, HW, C, n_global, training, using_bn, accumulate);
   SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_b");

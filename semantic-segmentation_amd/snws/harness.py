@@ -142,8 +142,6 @@ class GradBuckets:
 
     def _launch(self, bi):
         from . import ops
-        if self.flat_grad is not None and self.flat_grad.is_cuda or self.params[0].is_cuda:
-            ops.join_side_stream()      # weight gradients still running on the side stream belong to this bucket
         if self.slices is not None:
             lo, hi = self.slices[bi]
             flat = self.flat_grad[lo:hi]

@@ -116,49 +116,6 @@ def _numel(shape):
     return n
 
 
-# Weight gradients on a second stream.  Inside a backward pass the 3x3 weight-gradient kernels (matrix-core bound) of
-# parameters whose gradient lives in a flat buffer are enqueued on a side stream, so the memory-bound kernels of the
-# activation-gradient chain (SwitchNorm backward, gradient sums, the up-sampled-conv interpolation) run beside them
-# instead of between them.  The side stream is joined when the backward pass ends (an autograd final callback) and by
-# join_side_stream() before anything else reads a gradient mid-backward (the gradient all-reduce buckets).
-# Off by default: measured +1.6 % images/s on the 512^2 benchmark, but kernels of the two streams then share the chip
-# and per-kernel event timings stop describing one kernel.
-WGRAD_STREAM = int(os.environ.get("SNWS_WGRAD_STREAM", "0"))     # 0 off, 1 the 3x3 layers, 2 also the 1x1 tap convs
-_SIDE = {}      # device index -> [stream, work enqueued since the last join]
-
-
-def _has_sink(key, numel):
-    sink = GRAD_SINKS.get(key) if key is not None else None
-    return sink is not None and sink[4]() is not None and sink[2] == int(numel)
-
-
-def _side_stream(dev):
-    """The device's side stream, or None outside a backward pass (nothing would join it).  Every use queues its own
-    end-of-backward join (a pass that raised never ran the earlier ones); only the first to run has work to do."""
-    e = _SIDE.get(dev.index)
-    if e is None:
-        e = _SIDE[dev.index] = [torch.cuda.Stream(device=dev, priority=-1), False]
-    main = torch.cuda.current_stream(dev)
-
-    def join():
-        if e[1]:
-            e[1] = False
-            main.wait_stream(e[0])
-            torch.cuda.current_stream(dev).wait_stream(e[0])
-    try:
-        torch.autograd.Variable._execution_engine.queue_callback(join)
-    except RuntimeError:
-        return None
-    e[1] = True
-    return e[0]
-
-
-def join_side_stream():
-    """Makes the current stream of every device wait for the weight gradients enqueued so far."""
-    for idx, e in _SIDE.items():
-        torch.cuda.current_stream(idx).wait_stream(e[0])
-
-
 PROFILE_ONLY = None     # optional tuple of tag prefixes: only those launches are bracketed (events cost host time)
 
 
@@ -428,25 +385,8 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=N
             d = cfg.desc(N, H, W, C, C, lddy)
             L.call("snws_conv_direct_dgrad", ctypes.byref(d), dt, _ptr(dys), _ptr(prep.ohwi), _ptr(dx), _stream())
     if need_dw or need_db:
-        # with every result going to a flat-buffer slot the weight gradient feeds nothing but the optimizer
-        ok = used_mfma and prep.standardize and (not need_dw or _has_sink(grad_key(weight), weight.numel())) \
-            and (not need_db or _has_sink(bias_key, cfg.O))
-        dw, db = _beside(ok, dev, (dys, xs),
-                         lambda: _conv_backward_weights(dys, lddy, prep, saved, weight, need_dw, need_db, bias_key))
+        dw, db = _conv_backward_weights(dys, lddy, prep, saved, weight, need_dw, need_db, bias_key)
     return dx, dw, db
-
-
-def _beside(ok, dev, inputs, fn):
-    """Runs fn() on the device's side stream when allowed (ok, inside a backward pass), else on the current one.
-    inputs: the tensors fn reads that the current stream produced or may free."""
-    side = _side_stream(dev) if ok and WGRAD_STREAM else None
-    if side is None:
-        return fn()
-    side.wait_stream(torch.cuda.current_stream(dev))
-    for t in inputs:
-        t.record_stream(side)
-    with torch.cuda.stream(side):
-        return fn()
 
 
 def _conv_backward_weights(dys, lddy, prep, saved, weight, need_dw, need_db, bias_key):
@@ -971,22 +911,17 @@ class TapConvFn(torch.autograd.Function):
         (weight,) = ctx.saved_tensors
         tp = ctx.tp
         cfg = tp.cfg
-        dx, _, _ = conv_backward(dz, tp.prep, ctx.saved, None, ctx.needs_input_grad[0], False, False, None, ctx.in_segs)
+        dx, dwre, _ = conv_backward(dz, tp.prep, ctx.saved, None, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                    False, None, ctx.in_segs)
         ctx.in_segs = None
         dw = None
-        if ctx.needs_input_grad[1]:
-            saved = ctx.saved
-            dzs, lddz = as_nhwc(dz)
-
-            def weights():
-                dwre, _ = _conv_backward_weights(dzs, lddz, tp.prep, saved, None, True, False, None)
-                g = dwre.view(cfg.kh, cfg.kw, cfg.O, cfg.Ig).permute(2, 0, 1, 3).contiguous()
-                w32 = _f32c(weight)
-                dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), g.device, acc_ok=True)
-                L.call("snws_ws_bwd", _ptr(w32), _ptr(g), cfg.Ig, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw,
-                       int(grad_accumulates(dw)), _stream())
-                return grad_fold(dw)
-            dw = _beside(WGRAD_STREAM >= 2 and saved[3] and _has_sink(grad_key(weight), weight.numel()), dzs.device, (dzs, saved[0]), weights)
+        if dwre is not None:
+            g = dwre.view(cfg.kh, cfg.kw, cfg.O, cfg.Ig).permute(2, 0, 1, 3).contiguous()
+            w32 = _f32c(weight)
+            dw = grad_out(grad_key(weight), (cfg.O, cfg.Ig, cfg.kh, cfg.kw), g.device, acc_ok=True)
+            L.call("snws_ws_bwd", _ptr(w32), _ptr(g), cfg.Ig, _ptr(dw), cfg.O, cfg.Ig, cfg.kh, cfg.kw,
+                   int(grad_accumulates(dw)), _stream())
+            dw = grad_fold(dw)
             if dw is not None:
                 dw = dw.to(weight.dtype)
         ctx.saved = None

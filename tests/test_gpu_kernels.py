@@ -1279,58 +1279,6 @@ np.savez(sys.argv[1], **out)
 
 
 @pytest.mark.gpu
-def test_weight_gradients_on_side_stream_match_single_stream():
-    """SNWS_WGRAD_STREAM: the weight-gradient kernels of a backward pass enqueued on a second (high-priority) stream,
-    joined when the pass ends.  The activation-gradient chain is untouched, so every parameter gradient must equal
-    the single-stream run up to the summation order of the wgrad kernels' float atomics - and they must be complete
-    when backward() returns to a caller that only synchronizes the current stream."""
-    from modeling.UNet3p_SNws import UNet3p_SNws
-    from snws import ops
-    from snws.optim import FlatAdamW
-    torch.manual_seed(5)
-    model = UNet3p_SNws(14, 64, 10, 1, 1).to(DEV).train()
-    model.compute_dtype = torch.bfloat16
-    opt = FlatAdamW(list(model.parameters()), lr=2e-3, weight_decay=5e-4)
-    img = (torch.rand(2, 14, 96, 64) * 255.0).to(DEV)
-    lab = torch.randint(0, 10, (2, 96, 64)).to(DEV)
-    flat = {}
-    prev = ops.WGRAD_STREAM
-    used = []
-    orig = ops._side_stream
-
-    def counted(dev):
-        st = orig(dev)
-        used.append(st is not None)
-        return st
-    ops._side_stream = counted
-    try:
-        for mode in (0, 2, 0, 2):
-            ops.WGRAD_STREAM = mode
-            used.clear()
-            opt.zero_grad()
-            ops.weights_changed()
-            loss = torch.nn.functional.cross_entropy(model(img), lab) / 2
-            loss.backward()
-            torch.cuda.current_stream().synchronize()       # NOT a device-wide synchronize
-            g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
-            if mode:
-                assert used and all(used), "side stream not taken inside backward"
-                flat.setdefault("side", []).append(g)
-            else:
-                assert not used
-                flat.setdefault("main", []).append(g)
-    finally:
-        ops.WGRAD_STREAM = prev
-        ops._side_stream = orig
-    ref = flat["main"][0].double()
-    noise = float((flat["main"][1].double() - ref).norm() / ref.norm())        # atomics order, run to run
-    for g in flat["side"]:
-        err = float((g.double() - ref).norm() / ref.norm())
-        assert err < max(10 * noise, 1e-5), (err, noise)
-    print("side-stream weight gradients: rel diff %.2e (run-to-run noise %.2e)" % (err, noise))
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,with_bias,sliced", [(256, 128, True, False), (512, 256, False, False),
                                                        (128, 320, True, True)])
 def test_wide_plain_1x1_conv_gemm_route_matches_conv_kernel(cin, cout, with_bias, sliced):
