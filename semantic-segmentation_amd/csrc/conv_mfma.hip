@@ -1437,11 +1437,15 @@ extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, cons
   a.coTiles = cdiv(d->C_out, 64); a.ciTiles = c64 ? cdiv(d->C_in, 64) : 1;
   const int ntiles = d->N * a.tilesX * a.tilesY, npairs = a.coTiles * a.ciTiles;
   // Every workgroup ends with a 64x64x9 float-atomic flush (147 KB; the chip retires ~1.3 TB/s of atomics), so a
-  // launch wants few, long workgroups: one resident round (256 CUs x 2) unless each workgroup of a 2048-wide launch
-  // would still sweep >= 32 pixel tiles - then the finer split balances better than it costs.  (Measured: 64->64 @512^2
-  // 650 -> 813 TFLOP/s, 128->128 @256^2 703 -> 924 with one round; 320->320 @512^2 prefers 2048: 1057 vs 981.)
+  // launch of few channel-tile pairs wants few, long workgroups: one resident round (256 CUs x 2).  (Measured: 64->64
+  // @512^2 650 -> 813 TFLOP/s, 128->128 @256^2 703 -> 924 with one round instead of 2048 workgroups.)  With many pairs
+  // the workgroups of one pixel slice share its tiles through L2 only while they walk in step, and they drift apart
+  // over a long sweep: ~32 pixel tiles per workgroup is the measured optimum then (320->320: @512^2 981 TFLOP/s with
+  // 512 workgroups, 1045 with 2048, 1158 with 8192; @256^2 1077 / 1116 / 1078 with 2048 / 3072 / 8192).
   static const int forced_blocks = getenv("SNWS_WGRAD_BLOCKS") ? atoi(getenv("SNWS_WGRAD_BLOCKS")) : 0;
-  const int target_blocks = forced_blocks > 0 ? forced_blocks : ((int64_t)ntiles * npairs >= 32ll * 2048 ? 2048 : 512);
+  const int64_t sweep = (int64_t)ntiles * npairs;
+  const int target_blocks = forced_blocks > 0 ? forced_blocks
+                            : sweep >= 32ll * 2048 ? (int)(sweep / 32 < 8192 ? sweep / 32 : 8192) : 512;
   int splits = target_blocks / npairs;   // never more than target_blocks workgroups: two extra ones cost a whole extra round
   if (splits < 1) splits = 1;
   if (splits > ntiles) splits = ntiles;
