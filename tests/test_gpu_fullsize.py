@@ -1,0 +1,142 @@
+"""GPU parity at the benchmark's FULL layer sizes (batch 16, 512x512), where the CPU oracle would take minutes:
+size-independent exact properties instead of element-wise comparison.
+
+Convolution: with sparse small-integer operands every product and sum is exact in bf16 storage / f32 accumulation,
+so linear checksums of the outputs (weighted sums over pixels, or over channels) must EQUAL - bit for bit - the same
+checksums derived from the inputs by a different, cheap route (a few shifted element-wise products), for forward,
+dgrad and wgrad of the widest layer of UNet3p_SNws (320 -> 320, 3x3; modeling/UNet3p_SNws.py:91) and a 64 -> 64 one.
+SwitchNorm: the per-plane moments of the output must be the ones the mixing formula (modeling/snorm.py:45-81) predicts
+from per-plane moments of the input."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pixel_weights(N, H, W):
+    """q[n, y, x]: small integers that differ between neighbouring pixels and between images."""
+    n = torch.arange(N, device=DEV).view(N, 1, 1)
+    y = torch.arange(H, device=DEV).view(1, H, 1)
+    x = torch.arange(W, device=DEV).view(1, 1, W)
+    return ((n * 5 + y * 7 + x * 3) % 5 - 2).float()
+
+
+def _shift(t, dy, dx):
+    """u[..., y, x] = t[..., y + dy, x + dx], zero outside the image."""
+    H, W = t.shape[-2:]
+    u = torch.zeros_like(t)
+    ys, ye = max(0, -dy), min(H, H - dy)
+    xs, xe = max(0, -dx), min(W, W - dx)
+    u[..., ys:ye, xs:xe] = t[..., ys + dy:ye + dy, xs + dx:xe + dx]
+    return u
+
+
+@pytest.mark.parametrize("C_in,C_out", [(320, 320), (64, 64)])
+def test_conv3x3_full_size_exact_checksums(C_in, C_out):
+    from snws import ops
+    torch.manual_seed(C_in)
+    N, H, W = 16, 512, 512
+    # sparse operands: |y| stays far below 256 (exact in the bf16 the kernel stores), |dw| below 2^24 (exact in f32)
+    x = (torch.rand(N, H, W, C_in, device=DEV) < 0.05).to(torch.bfloat16).permute(0, 3, 1, 2)
+    w = torch.randint(-1, 2, (C_out, C_in, 3, 3), device=DEV).float() * (torch.rand(C_out, C_in, 3, 3, device=DEV) < 0.1)
+    dy = (torch.randint(-1, 2, (N, H, W, C_out), device=DEV).float() *
+          (torch.rand(N, H, W, C_out, device=DEV) < 0.1)).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randint(-2, 3, (C_out,), device=DEV).float()
+    cfg = ops.ConvCfg(w.shape, 1, 1, 1, 1)
+    prep = ops.PreparedWeight(w, cfg, True, standardize=False)
+    y, stat, saved = ops.conv_forward(x, prep, bias, want_stats=True)
+    assert saved[3], "the MFMA path was not taken"
+    dx, dw, db = ops.conv_backward(dy, prep, saved, w, True, True, True)
+    torch.cuda.synchronize()
+    q = _pixel_weights(N, H, W)
+
+    # ---- forward: sum_p q[p] * y[co, p] = sum_{ci,t} w[co,ci,t] * sum_p q[p] * x[ci, p + t - 1]  (+ bias * sum q)
+    assert float(y.float().abs().max()) < 200.0
+    lhs = (y.double() * q.double().unsqueeze(1)).sum((0, 2, 3))
+    xf = x.float()
+    A = torch.empty(C_in, 3, 3, dtype=torch.float64, device=DEV)
+    for kh in range(3):
+        for kw in range(3):
+            qs = _shift(q, -(kh - 1), -(kw - 1))          # q at the output pixel that reads input pixel p through this tap
+            A[:, kh, kw] = (xf * qs.unsqueeze(1)).double().sum((0, 2, 3))
+    rhs = torch.einsum("oikl,ikl->o", w.double(), A) + bias.double() * q.double().sum()
+    assert torch.equal(lhs, rhs), float((lhs - rhs).abs().max())
+
+    # ---- the statistics the epilogue hands SwitchNorm: sum and sum of squares of (y - bias) per (image, channel)
+    tot = stat.double().sum(1)                            # (N, C_out, 2)
+    yc = y.double() - bias.double().view(1, -1, 1, 1)
+    assert torch.equal(tot[..., 0], yc.sum((2, 3)))
+    assert torch.equal(tot[..., 1], (yc * yc).sum((2, 3)))
+
+    # ---- dgrad: sum_p q[p] * dx[ci, p] = sum_{co,t} w[co,ci,t] * sum_p' dy[co, p'] * q[p' + t - 1]
+    assert float(dx.float().abs().max()) < 200.0
+    lhs = (dx.double() * q.double().unsqueeze(1)).sum((0, 2, 3))
+    dyf = dy.float()
+    B = torch.empty(C_out, 3, 3, dtype=torch.float64, device=DEV)
+    for kh in range(3):
+        for kw in range(3):
+            qs = _shift(q, kh - 1, kw - 1)
+            B[:, kh, kw] = (dyf * qs.unsqueeze(1)).double().sum((0, 2, 3))
+    rhs = torch.einsum("oikl,okl->i", w.double(), B)
+    assert torch.equal(lhs, rhs), float((lhs - rhs).abs().max())
+
+    # ---- wgrad: dw[co,ci,t] = sum_p dy[co,p] * x[ci, p + t - 1]; checked through channel-weighted sums on both sides
+    r = (torch.arange(C_in, device=DEV) % 3 - 1).float()
+    s = (torch.arange(C_out, device=DEV) % 5 - 2).float()
+    xr = torch.einsum("nihw,i->nhw", xf, r)               # integer-valued, exact
+    ds = torch.einsum("nohw,o->nhw", dyf, s)
+    for kh in range(3):
+        for kw in range(3):
+            lhs = torch.einsum("oi,i->o", dw[:, :, kh, kw].double(), r.double())
+            rhs = (dyf * _shift(xr, kh - 1, kw - 1).unsqueeze(1)).double().sum((0, 2, 3))
+            assert torch.equal(lhs, rhs), (kh, kw, float((lhs - rhs).abs().max()))
+            lhs = torch.einsum("oi,o->i", dw[:, :, kh, kw].double(), s.double())
+            rhs = (xf * _shift(ds, -(kh - 1), -(kw - 1)).unsqueeze(1)).double().sum((0, 2, 3))
+            assert torch.equal(lhs, rhs), (kh, kw, float((lhs - rhs).abs().max()))
+    assert torch.equal(db.double(), dyf.double().sum((0, 2, 3)))
+
+
+def test_switchnorm_full_size_plane_moments():
+    """64 channels at 512x512, batch 16, bf16 - the SwitchNorm call with the most elements per channel.  Without the
+    ReLU, every (image, channel) plane of the output must have mean gamma*(mu_in - m)*r + beta and variance
+    gamma^2 * var_in * r^2, with m, r from the IN/LN/BN mix of the input's plane moments."""
+    import modeling.snorm as sn
+    from snws import ops
+    torch.manual_seed(2)
+    N, C, H, W = 16, 64, 512, 512
+    mod = sn.SwitchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        mod.weight.copy_(torch.rand(1, C, 1, 1) + 0.5)
+        mod.bias.copy_(torch.randn(1, C, 1, 1) * 0.3)
+        mod.mean_weight.copy_(torch.tensor([0.3, -0.2, 0.5]))
+        mod.var_weight.copy_(torch.tensor([-0.1, 0.4, 0.2]))
+    scale = torch.rand(N, 1, 1, C, device=DEV) * 2 + 0.5
+    shift = torch.randn(N, 1, 1, C, device=DEV)
+    x = (torch.randn(N, H, W, C, device=DEV) * scale + shift).to(torch.bfloat16).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        y, _ = ops.sn_forward(x, ops.SNParams(mod), relu=False)
+    torch.cuda.synchronize()
+    xd = x.double()
+    mu_in = xd.mean((2, 3))
+    var_in = xd.var((2, 3), unbiased=True)
+    mu_ln = mu_in.mean(1, keepdim=True)
+    var_ln = (var_in + mu_in ** 2).mean(1, keepdim=True) - mu_ln ** 2
+    mu_bn = mu_in.mean(0, keepdim=True)
+    var_bn = (var_in + mu_in ** 2).mean(0, keepdim=True) - mu_bn ** 2
+    a = torch.softmax(mod.mean_weight.detach().double(), 0)
+    b = torch.softmax(mod.var_weight.detach().double(), 0)
+    m = a[0] * mu_in + a[1] * mu_ln + a[2] * mu_bn
+    v = b[0] * var_in + b[1] * var_ln + b[2] * var_bn
+    r = 1.0 / torch.sqrt(v + mod.eps)
+    g, be = mod.weight.detach().double().view(1, C), mod.bias.detach().double().view(1, C)
+    want_mean = g * (mu_in - m) * r + be
+    want_var = g ** 2 * var_in * r ** 2
+    yd = y.double()
+    got_mean, got_var = yd.mean((2, 3)), yd.var((2, 3), unbiased=True)
+    # bf16 output rounding is unbiased noise of relative size 2^-9 per element: it averages out over 262144 pixels
+    assert float((got_mean - want_mean).abs().max()) < 2e-3 * float(want_mean.abs().max() + 1)
+    assert float(((got_var - want_var) / want_var).abs().max()) < 5e-3
+    # running buffers after this first call: 0.003 * the batch moments (modeling/snorm.py:57-60)
+    assert float((mod.running_mean.view(-1).double() - 0.003 * mu_bn.view(-1)).abs().max()) < 1e-5
+    assert float((mod.running_var.view(-1).double() - 0.003 * var_bn.view(-1)).abs().max()) < 1e-4
