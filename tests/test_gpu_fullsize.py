@@ -140,3 +140,36 @@ def test_switchnorm_full_size_plane_moments():
     # running buffers after this first call: 0.003 * the batch moments (modeling/snorm.py:57-60)
     assert float((mod.running_mean.view(-1).double() - 0.003 * mu_bn.view(-1)).abs().max()) < 1e-5
     assert float((mod.running_var.view(-1).double() - 0.003 * var_bn.view(-1)).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_switchnorm_backward_full_size_invariances(relu):
+    """SwitchNorm (IN, LN and BN branches alike) does not change when a constant is added to its whole input, nor -
+    up to eps - when the input is scaled.  Its input gradient is therefore orthogonal to the all-ones direction and
+    to the input itself, whatever the incoming gradient and with or without the fused ReLU: two scalar identities
+    that involve every element of dx at the full 16 x 64 x 512 x 512 size."""
+    import modeling.snorm as sn
+    from snws import ops
+    torch.manual_seed(4)
+    N, C, H, W = 16, 64, 512, 512
+    mod = sn.SwitchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        mod.weight.copy_(torch.rand(1, C, 1, 1) + 0.5)
+        mod.bias.copy_(torch.randn(1, C, 1, 1) * 0.3)
+        mod.mean_weight.copy_(torch.tensor([0.3, -0.2, 0.5]))
+        mod.var_weight.copy_(torch.tensor([-0.1, 0.4, 0.2]))
+    scale = torch.rand(N, 1, 1, C, device=DEV) * 2 + 0.5
+    shift = torch.randn(N, 1, 1, C, device=DEV)
+    x = (torch.randn(N, H, W, C, device=DEV) * scale + shift).to(torch.bfloat16).permute(0, 3, 1, 2)
+    dy = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        y, saved = ops.sn_forward(x, ops.SNParams(mod), relu=relu)
+        dx = ops.sn_backward(dy, saved)[0]
+    torch.cuda.synchronize()
+    dxd, xd = dx.double(), x.double()
+    n_el = float(dxd.numel())
+    norm_dx = float(dxd.norm())
+    assert norm_dx > 0
+    cos_ones = float(dxd.sum()) / (n_el ** 0.5 * norm_dx)
+    cos_x = float((dxd * xd).sum()) / (float(xd.norm()) * norm_dx)
+    assert abs(cos_ones) < 2e-4 and abs(cos_x) < 2e-4, (cos_ones, cos_x)
