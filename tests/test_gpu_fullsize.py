@@ -173,3 +173,96 @@ def test_switchnorm_backward_full_size_invariances(relu):
     cos_ones = float(dxd.sum()) / (n_el ** 0.5 * norm_dx)
     cos_x = float((dxd * xd).sum()) / (float(xd.norm()) * norm_dx)
     assert abs(cos_ones) < 2e-4 and abs(cos_x) < 2e-4, (cos_ones, cos_x)
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def test_conv3x3_full_size_adjoint_identities():
+    """Random (non-integer) bf16 data on the 320 -> 320 layer at full size: forward, dgrad and wgrad are the three
+    faces of one trilinear form, <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>.  dy is chosen correlated
+    with the output so the form is far from zero; the only inexact step is the bf16 rounding of y and dx."""
+    from snws import ops
+    torch.manual_seed(9)
+    N, H, W, C = 16, 512, 512, 320
+    x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+    w = (torch.randn(C, C, 3, 3, device=DEV) / (9 * C) ** 0.5).to(torch.bfloat16).float()
+    cfg = ops.ConvCfg(w.shape, 1, 1, 1, 1)
+    prep = ops.PreparedWeight(w, cfg, True, standardize=False)
+    y, _, saved = ops.conv_forward(x, prep, None)
+    dy = (y.float() * 0.5 + torch.randn(N, H, W, C, device=DEV).permute(0, 3, 1, 2)).to(torch.bfloat16)
+    dx, dw, _ = ops.conv_backward(dy, prep, saved, w, True, True, False)
+    torch.cuda.synchronize()
+    f, g, h = _dot(y, dy), _dot(x, dx), _dot(w, dw)
+    assert f > 0.3 * float(y.double().norm()) ** 2 * 0.5
+    assert abs(f - g) < 1e-3 * abs(f) and abs(f - h) < 1e-3 * abs(f), (f, g, h)
+
+
+@pytest.mark.parametrize("k", [2, 4, 8, 16])
+def test_upconv_full_size_constant_maps_and_adjoint(k):
+    """conv3x3(upsample_k(x)) computed from the nine tap maps Z_t = W_t x, output 16 x 64 x 512 x 512.
+    (a) Tap maps that are constant over the image interpolate to themselves, so the output must be EXACTLY
+    bias + the sum of the taps that fall inside the image at each pixel - at every pixel, which checks the
+    interpolation weights' partition of unity and the border masks everywhere.
+    (b) Backward is the transpose of forward: <fwd(Z), dY> = <Z, bwd(dY)> for random data."""
+    import ctypes
+    from snws import _lib as L
+    from snws import ops
+    torch.manual_seed(k)
+    N, CO, HO = 16, 64, 512
+    h = HO // k
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fwd(z, bias):
+        y = torch.empty(N, HO, HO, CO, dtype=torch.bfloat16, device=DEV)
+        T = L.lib().snws_upconv_stat_tiles(HO, HO)
+        stat = torch.empty((N, T, CO, 2), dtype=torch.float32, device=DEV)
+        L.call("snws_upconv_fwd_stats", z.data_ptr(), 9 * CO, y.data_ptr(), CO, None if bias is None else bias.data_ptr(),
+               L.SNWS_BF16, N, h, h, CO, k, 3, stat.data_ptr(), st)
+        return y, stat
+
+    c = torch.randint(-3, 4, (9, CO), device=DEV).float()
+    bias = torch.randint(-2, 3, (CO,), device=DEV).float()
+    z = c.view(1, 1, 1, 9 * CO).expand(N, h, h, 9 * CO).to(torch.bfloat16).contiguous()
+    y, stat = fwd(z, bias)
+    want = bias.view(1, 1, 1, CO).expand(N, HO, HO, CO).clone()
+    for kh in range(3):
+        for kw in range(3):
+            m = torch.zeros(HO, HO, device=DEV)
+            m[max(0, 1 - kh):HO - max(0, kh - 1), max(0, 1 - kw):HO - max(0, kw - 1)] = 1.0
+            want += m.view(1, HO, HO, 1) * c[kh * 3 + kw].view(1, 1, 1, CO)
+    assert torch.equal(y.float(), want)
+    tot = stat.double().sum(1)
+    yc = (y.float() - bias.view(1, 1, 1, CO)).double()
+    assert torch.equal(tot[..., 0], yc.sum((1, 2))) and torch.equal(tot[..., 1], (yc * yc).sum((1, 2)))
+
+    z = torch.randn(N, h, h, 9 * CO, device=DEV).to(torch.bfloat16)
+    y, _ = fwd(z, None)
+    dy = (y.float() * 0.5 + torch.randn(N, HO, HO, CO, device=DEV)).to(torch.bfloat16)
+    dz = torch.empty_like(z)
+    L.call("snws_upconv_bwd", dy.data_ptr(), CO, dz.data_ptr(), 9 * CO, L.SNWS_BF16, N, h, h, CO, k, 3, st)
+    torch.cuda.synchronize()
+    f, g = _dot(y, dy), _dot(z, dz)
+    assert f > 0 and abs(f - g) < 2e-3 * abs(f), (f, g)
+
+
+@pytest.mark.parametrize("mode,k", [("max", 2), ("max", 8), ("bilinear", 2), ("bilinear", 16)])
+def test_resample_full_size_adjoint(mode, k):
+    """MaxPool2d(k, k, ceil_mode=True) and bilinear Upsample(k) at the 512x512 end of the skip connections
+    (modeling/UNet3p_SNws.py:49-55): backward is the transpose of (the selection made by) forward.  The pooling
+    windows do not overlap, so for max-pooling both sides are sums of the same products and agree to double precision;
+    the interpolation rounds y and dx to bf16."""
+    from snws import ops
+    torch.manual_seed(k)
+    N, C = 16, 64
+    S = 512 if mode == "max" else 512 // k
+    x = torch.randn(N, S, S, C, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2).requires_grad_(True)
+    y = ops.max_pool_ceil(x, k) if mode == "max" else ops.upsample_bilinear(x, k)
+    assert tuple(y.shape) == ((N, C, S // k, S // k) if mode == "max" else (N, C, S * k, S * k))
+    dy = (y.detach().float() * 0.5 + torch.randn_like(y, dtype=torch.float32)).to(torch.bfloat16)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    f, g = _dot(y.detach(), dy), _dot(x.detach(), x.grad)
+    tol = 1e-12 if mode == "max" else 2e-3
+    assert f > 0 and abs(f - g) <= tol * abs(f), (f, g)
