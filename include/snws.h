@@ -189,6 +189,13 @@ int snws_sn_bwd_mix_b(const float* ctx, float* ctxb, const float* packb, const f
 int snws_sn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask, int64_t ldy,
                       void* dx, int64_t lddx, int dtype, const float* ctx, const float* ctxb, const float* beta,
                       int N, int64_t HW, int C, int relu, void* stream);
+/* Pass 2 of the residual block's second SwitchNorm (relu(SwitchNorm(conv) + residual),
+ * modeling/UNet3p_res_ocr_SNws.py:152-159): as snws_sn_bwd_apply with relu = 1 and the mask taken from the block
+ * output y_for_mask (required), and the masked incoming gradient dy' = [y > 0] * dy - the gradient of the residual
+ * input - is stored to dres in the same pass (replaces autograd's threshold-backward of `out += residual; relu`). */
+int snws_sn_bwd_apply_res(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask, int64_t ldy,
+                          void* dx, int64_t lddx, void* dres, int64_t lddres, int dtype, const float* ctx,
+                          const float* ctxb, const float* beta, int N, int64_t HW, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batch normalisation on the same streaming kernels - replaces nn.BatchNorm2d (+ nn.ReLU) of the OCR head

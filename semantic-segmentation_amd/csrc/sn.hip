@@ -623,7 +623,8 @@ __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------- backward pass 2
-template <typename T, int V, bool RELU, bool YMASK>
+// DRES: also store the masked incoming gradient (the gradient of a residual input added before the ReLU)
+template <typename T, int V, bool RELU, bool YMASK, bool DRES = false>
 __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy,
                                                                   const T* __restrict__ x, int64_t ldx,
                                                                   const T* __restrict__ ym, int64_t ldy,
@@ -631,7 +632,8 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
                                                                   const float* __restrict__ ctx,
                                                                   const float* __restrict__ ctxb,
                                                                   const float* __restrict__ beta, int N, int64_t HW,
-                                                                  int C, int PT, SnMap m) {
+                                                                  int C, int PT, SnMap m,
+                                                                  T* __restrict__ dres = nullptr, int64_t lddr = 0) {
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int64_t p0 = (int64_t)t * PT;
   const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
@@ -641,6 +643,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
   const T* dn = dy + (int64_t)n * HW * lddy;
   const T* yn = YMASK ? ym + (int64_t)n * HW * ldy : nullptr;
   T* on = dx + (int64_t)n * HW * lddx;
+  T* rn = DRES ? dres + (int64_t)n * HW * lddr : nullptr;
   const int cgl = tid % m.cgb, prow = tid / m.cgb;
   if (tid >= m.active) return;
   for (int cg0 = 0; cg0 < m.CG; cg0 += m.cgb) {
@@ -676,6 +679,13 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
           g0[v] = k0 ? g0[v] : 0.f;
           g1[v] = k1 ? g1[v] : 0.f;
         }
+      }
+      if (DRES) {
+        VecNT<T, V>::store(rn + p * lddr + co, g0);
+        VecNT<T, V>::store(rn + (p + m.PR) * lddr + co, g1);
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
         g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
         g1[v] = fmaf(sc[v], g1[v], fmaf(Bc[v], a1[v], Kc[v]));
       }
@@ -693,8 +703,10 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
           bool k0 = YMASK ? (y0[v] > 0.f) : (fmaf(a0[v] - mu[v], sc[v], be[v]) > 0.f);
           g0[v] = k0 ? g0[v] : 0.f;
         }
-        g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
       }
+      if (DRES) VecNT<T, V>::store(rn + p * lddr + co, g0);
+#pragma unroll
+      for (int v = 0; v < V; ++v) g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
       VecNT<T, V>::store(on + p * lddx + co, g0);
     }
   }
@@ -769,13 +781,15 @@ int run_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, con
 template <typename T, int V>
 int run_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* ym, int64_t ldy, void* dx,
                   int64_t lddx, const float* ctx, const float* ctxb, const float* beta, int N, int64_t HW, int C,
-                  int relu, hipStream_t st) {
+                  int relu, hipStream_t st, void* dres = nullptr, int64_t lddr = 0) {
   const SnMap m = sn_map(C, V);
   const int T_ = sn_tiles(N, HW, C);
   const int PT = (int)cdiv64(HW, T_);
   dim3 grid(T_, N);
 #define BA(R, Y) sn_bwd_apply_kernel<T, V, R, Y><<<grid, SN_THREADS, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, (T*)dx, lddx, ctx, ctxb, beta, N, HW, C, PT, m)
-  if (relu) { if (ym) BA(true, true); else BA(true, false); }
+  if (dres)    // the caller checked relu && ym
+    sn_bwd_apply_kernel<T, V, true, true, true><<<grid, SN_THREADS, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, (T*)dx, lddx, ctx, ctxb, beta, N, HW, C, PT, m, (T*)dres, lddr);
+  else if (relu) { if (ym) BA(true, true); else BA(true, false); }
   else BA(false, false);
 #undef BA
   SNWS_LAUNCH_CHECK("snws_sn_bwd_apply");
@@ -914,4 +928,23 @@ extern "C" int snws_sn_bwd_apply(const void* dy, int64_t lddy, const void* x, in
   if (can_vec<bf16_t>(C, {dy, x, y_for_mask, dx}, {lddy, ldx, y_for_mask ? ldy : 0, lddx}))
     return run_bwd_apply<bf16_t, 8>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st);
   return run_bwd_apply<bf16_t, 1>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st);
+}
+
+extern "C" int snws_sn_bwd_apply_res(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y_for_mask,
+                                     int64_t ldy, void* dx, int64_t lddx, void* dres, int64_t lddres, int dtype,
+                                     const float* ctx, const float* ctxb, const float* beta, int N, int64_t HW, int C,
+                                     void* stream) {
+  SN_COMMON_CHECKS("snws_sn_bwd_apply_res");
+  SNWS_CHECK_ARG(dy && x && y_for_mask && dx && dres && ctx && ctxb && beta, "snws_sn_bwd_apply_res: NULL pointer");
+  SNWS_CHECK_ARG(lddy >= C && ldx >= C && lddx >= C && ldy >= C && lddres >= C,
+                 "snws_sn_bwd_apply_res: pixel stride smaller than C");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SNWS_F32) {
+    if (can_vec<float>(C, {dy, x, y_for_mask, dx, dres}, {lddy, ldx, ldy, lddx, lddres}))
+      return run_bwd_apply<float, 4>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
+    return run_bwd_apply<float, 1>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
+  }
+  if (can_vec<bf16_t>(C, {dy, x, y_for_mask, dx, dres}, {lddy, ldx, ldy, lddx, lddres}))
+    return run_bwd_apply<bf16_t, 8>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
+  return run_bwd_apply<bf16_t, 1>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
 }

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "snws_sn_bwd_mix_b": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_float, c_int, c_int, c_int, P]),
     "snws_sn_bwd_apply": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64,
                                   c_int, c_int, P]),
+    "snws_sn_bwd_apply_res": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int,
+                                      c_int64, c_int, P]),
     "snws_upconv_fwd": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_upconv_stat_tiles": (c_int, [c_int, c_int]),
     "snws_upconv_fwd_stats": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -547,9 +547,11 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     return y, saved
 
 
-def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None):
+def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
     """Returns (dx, dgamma (C), dbeta (C), dmean_weight, dvar_weight[, dx_sum (C)]).  dx_sum is the closed-form
-    per-channel sum of dx, i.e. the gradient of a bias added just before the normalisation."""
+    per-channel sum of dx, i.e. the gradient of a bias added just before the normalisation.  dres_dtype (residual
+    variant only): also produce the gradient of the residual input, [y > 0] * dy, in the apply pass when it has the
+    activation dtype; it is left in s["dres"]."""
     N, C, H, W = s["shape"]
     HW = H * W
     lib = L.lib()
@@ -591,9 +593,15 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None):
     L.call("snws_sn_bwd_mix_b", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), _ptr(s["mw"]), _ptr(s["vw"]), None, None,
            _ptr(dmw), _ptr(dvw), _ptr(dxsum), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), acc_b, st)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
-    _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]),
-            s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C,
-            int(s["relu"]), st)
+    if dres_dtype is not None and dres_dtype == dys.dtype and yms is not None and s["relu"]:
+        dres = s["dres"] = new_nhwc(N, C, H, W, dys.dtype, dev)
+        _launch("sn_bwd_apply", 4.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply_res", _ptr(dys), lddy,
+                _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, _ptr(dx), C, _ptr(dres), C, dt, _ptr(s["ctx"]), _ptr(ctxb),
+                _ptr(s["beta"]), N, HW, C, st)
+    else:
+        _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy,
+                _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]),
+                N, HW, C, int(s["relu"]), st)
     if want_dx_sum:
         return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw), grad_fold(dxsum)
     return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw)
@@ -865,9 +873,10 @@ class ConvSnAddReluFn(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         y = ctx.sn["y"]
-        dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn)
-        dres = None
-        if ctx.needs_input_grad[9]:
+        want_res = ctx.needs_input_grad[9]
+        dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn, dres_dtype=ctx.res_dtype if want_res else None)
+        dres = ctx.sn.pop("dres", None)
+        if want_res and dres is None:
             dres = torch.where(y > 0, dy.to(y.dtype), torch.zeros((), dtype=y.dtype, device=y.device)).to(ctx.res_dtype)
         ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]

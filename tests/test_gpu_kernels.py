@@ -413,6 +413,53 @@ def test_resnet_basic_block_vs_oracle(shape, dtype, tol):
         assert relerr(v.grad.float().view(-1), ref.view(-1)) < lim, k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_gradient_from_the_apply_pass_equals_threshold_backward(dtype):
+    """The gradient of the residual input of relu(SwitchNorm(conv(t)) + x) is [y > 0] * dy.  The backward apply pass
+    of the block's second SwitchNorm stores it (snws_sn_bwd_apply_res); it must be taken, and must equal autograd's own
+    threshold-backward bit for bit, as must the conv-path gradient next to it."""
+    from modeling.blocks import Resnet_BasicBlock
+    from snws import _lib as L
+    torch.manual_seed(8)
+    N, C, H, W = 2, 64, 24, 40
+    blk = Resnet_BasicBlock(C, C).to(DEV).train()
+    x = torch.randn(N, C, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, C, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    calls = []
+    orig = L.call
+
+    def counted(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    L.call = counted
+    try:
+        xg = x.clone().requires_grad_(True)
+        y = blk(xg)
+        y.backward(dy)
+    finally:
+        L.call = orig
+    assert "snws_sn_bwd_apply_res" in calls
+    # the block computes relu(f(x) + x): d/dx = (conv path) + [y > 0] * dy; isolate the skip term with a detached twin
+    xh = x.clone().requires_grad_(True)
+    blk.zero_grad()
+    y2 = blk(xh)        # second pass over the same modules: the running buffers move, outputs and gradients do not
+    skip = torch.where(y2.detach() > 0, dy, torch.zeros((), dtype=dtype, device=DEV))
+    from snws import ops
+    real = ops.sn_backward
+
+    def no_res(dy_, s, **kw):
+        kw.pop("dres_dtype", None)
+        return real(dy_, s, **kw)
+    ops.sn_backward = no_res
+    try:
+        y2.backward(dy)
+    finally:
+        ops.sn_backward = real
+    assert torch.equal(y2, y)
+    assert torch.equal(xh.grad, xg.grad)
+    assert float(skip.abs().sum()) > 0
+
+
 def test_switchnorm_errors():
     import modeling.snorm as sn
     m = sn.SwitchNorm2d(4).to(DEV)
