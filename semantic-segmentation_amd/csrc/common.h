@@ -33,6 +33,19 @@ void snws_set_error(const char* fmt, ...);
     }                                                                                 \
   } while (0)
 
+// hipFuncSetAttribute applies to the current device only: one flag per device and kernel, so a process that drives
+// several GPUs configures each of them (std::atomic: the first calls may come from different host threads)
+#include <atomic>
+struct PerDeviceOnce {
+  std::atomic<bool> done[64];
+  // the flag of the current device, or nullptr when the device cannot be determined / is out of range (then: always configure)
+  std::atomic<bool>* flag() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+    return &done[d];
+  }
+};
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -1237,15 +1237,16 @@ template <int KC, int TAPS, bool DB, bool M16, bool BWR>
 int launch_fwd_v(const std::conditional_t<BWR, FwdArgsBwr, FwdArgs>& a, unsigned grid, hipStream_t st) {
   using G = FwdGeom<KC, TAPS>;
   constexpr int LDS = DB ? G::LDS_BYTES_DB : G::LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<KC, TAPS, DB, M16, BWR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SNWS_ERR_HIP;
     }
-    attr_set = true;
+    if (attr_set) attr_set->store(true, std::memory_order_release);
   }
   conv_fwd_kernel<KC, TAPS, DB, M16, BWR><<<grid, 256, LDS, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_fwd");
@@ -1326,15 +1327,16 @@ int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_ru
 template <int CIC, int TAPS>
 int launch_wgrad(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<CIC, TAPS>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<CIC, TAPS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SNWS_ERR_HIP;
     }
-    attr_set = true;
+    if (attr_set) attr_set->store(true, std::memory_order_release);
   }
   conv_wgrad_kernel<CIC, TAPS><<<grid, 256, G::LDS_BYTES, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
@@ -1344,15 +1346,16 @@ int launch_wgrad(const WgradArgs& a, unsigned grid, hipStream_t st) {
 template <bool BIAS>
 int launch_wgrad1(const WgradArgs& a, unsigned grid, hipStream_t st) {
   constexpr int LDS = WgGeom<64, 1>::LDS_BYTES > 65536 + 1024 ? WgGeom<64, 1>::LDS_BYTES : 65536 + 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1_kernel<BIAS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SNWS_ERR_HIP;
     }
-    attr_set = true;
+    if (attr_set) attr_set->store(true, std::memory_order_release);
   }
   conv_wgrad1_kernel<BIAS><<<grid, 256, LDS, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
@@ -1362,15 +1365,16 @@ int launch_wgrad1(const WgradArgs& a, unsigned grid, hipStream_t st) {
 template <bool BIAS>
 int launch_wgrad1w(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
   constexpr int LDS = 65536 + 4 * 128 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1w_kernel<BIAS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SNWS_ERR_HIP;
     }
-    attr_set = true;
+    if (attr_set) attr_set->store(true, std::memory_order_release);
   }
   conv_wgrad1w_kernel<BIAS><<<grid, 256, LDS, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
@@ -1380,15 +1384,16 @@ int launch_wgrad1w(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
 template <bool BIAS>
 int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<64, 9>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9_kernel<BIAS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SNWS_ERR_HIP;
     }
-    attr_set = true;
+    if (attr_set) attr_set->store(true, std::memory_order_release);
   }
   conv_wgrad9_kernel<BIAS><<<grid, 256, G::LDS_BYTES, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");

@@ -448,15 +448,16 @@ template <int K>
 int launch_fwd_lds_k(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, float* stat, int N, int h, int w,
                      int Co, hipStream_t st) {
   constexpr int LDS = up_lds_bytes<K>() < 2048 ? 2048 : up_lds_bytes<K>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_fwd_lds_kernel<K>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       snws_set_error("upconv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SNWS_ERR_HIP;
     }
-    attr_set = true;
+    if (attr_set) attr_set->store(true, std::memory_order_release);
   }
   const int H = h * K, W = w * K;
   const int tilesX = cdiv(W, SEP_TW), tilesY = cdiv(H, SEP_TH);
