@@ -45,5 +45,23 @@ out += ["", "GPU time per step %.1f ms (sum of kernel durations / %d steps)." % 
 for x in rows[:28]:
     out.append("| `%s` | %d | %.2f | %.1f | %.1f |" % (short(x["Name"]), int(x["Calls"]), float(x["TotalDurationNs"]) / steps / 1e6,
                                                       float(x["AverageNs"]) / 1e3, 100 * float(x["TotalDurationNs"]) / tot))
+# the other files of the directory, and the per-kernel HBM traffic table when its summary is there
+out += ["", "Other files:", "",
+        "* `r01_pmc_bench_conv.json` - HBM bytes per launch of the dominant kernel inside the same workload (`tools/run_pmc_bench.sh`: "
+        "two `rocprofv3 --pmc` runs, FETCH_SIZE and WRITE_SIZE, no tracing beside `--kernel-trace`; FETCH_SIZE doubled as gfx950 "
+        "tallies 128-byte requests at 64 bytes); `bench.py` copies it into `roofline.traffic`.",
+        "* `r01_pmc_bench_all_kernels.json` - the same two passes for EVERY kernel of the step (table below).",
+        "* `r01_res_ocr_bs16_512_kernel_stats.csv`, `r01_bench_res_ocr_gpus1.json` - `bench.py --model unet3p_res_ocr` "
+        "(UNet3p_res_ocr_SNws, batch 16, 512x512): kernel summary and JSON line.",
+        "* `r01_bench_disk_gpus1.json` - `bench.py --disk`: adds full-disk tiled inference (36 tiles of one 2748x2748 disk)."]
+allk = os.path.join(ROOT, "profiles", "r01_pmc_bench_all_kernels.json")
+if os.path.exists(allk):
+    ks = json.load(open(allk))["kernels"]
+    out += ["", "HBM traffic per launch from the PMC passes (MB; algorithmic traffic of the streaming SwitchNorm passes is "
+            "2 tensors forward, 3 backward - the counters show exactly that ratio, i.e. no wasted re-reads):", "",
+            "| kernel | launches | fetch MB | write MB |", "|---|---|---|---|"]
+    for k in ks[:18]:
+        out.append("| `%s` | %d | %.1f | %.1f |" % (short(k["kernel"]), k["launches"], k["fetch_bytes_per_launch"] / 1e6,
+                                                   k["write_bytes_per_launch"] / 1e6))
 open(os.path.join(ROOT, "profiles", "README.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out[:12]))
