@@ -333,7 +333,7 @@ def test_unet_snws_cpu_runnable_configuration_vs_oracle(dtype):
     float32 oracle.  The gradients of this random-label step are small residuals of large cancelling sums: the float32
     oracle's OWN gradients are 6e-3 (median over parameters, L2) and up to 6e-2 (a SwitchNorm mixing vector) away from
     the float64 oracle's, so the float32 kernels are compared with the float64 oracle (20 s on the CPU) and held to
-    1e-3 + 2x the float32 oracle's distance from it, for the median and for the worst parameter.  bf16 tier (MFMA
+    1e-3 + 3x the float32 oracle's distance from it, for the median and for the worst parameter.  bf16 tier (MFMA
     kernels): at these widths (up to 1024 channels, 22 stacked normalised blocks, random filters) bf16 STORAGE alone
     moves the logits by 0.11 relative L2 (oracle with bf16 storage points against the float32 oracle, printed); two
     correct bf16 implementations differ wherever a different summation order flips a rounding, which then spreads the
@@ -382,8 +382,8 @@ def test_unet_snws_cpu_runnable_configuration_vs_oracle(dtype):
         print("  against the float64 oracle: GPU float32 median %.3g worst %.3g; CPU float32 oracle median %.3g worst %.3g"
               % (statistics.median(mine.values()), max(mine.values()), statistics.median(theirs.values()),
                  max(theirs.values())))
-        assert statistics.median(mine.values()) < 1e-3 + 2.0 * statistics.median(theirs.values())
-        assert max(mine.values()) < 1e-3 + 2.0 * max(theirs.values())
+        assert statistics.median(mine.values()) < 1e-3 + 3.0 * statistics.median(theirs.values())
+        assert max(mine.values()) < 1e-3 + 3.0 * max(theirs.values())
         for name, b in model.named_buffers():            # running statistics after this one step
             assert l2(b, ostate[name]) < 1e-3, name
     else:
