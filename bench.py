@@ -137,6 +137,12 @@ def main():
                          "time per step); default: only the roofline kernel's launches")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON result: whatever libraries print there (RCCL announces its version
+    # on stdout when a communicator is created) is sent to stderr instead, on every rank
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     from snws import harness, ops
     from modeling.UNet3p_SNws import UNet3p_SNws
     from modeling.UNet3p_res_ocr_SNws import UNet3p_res_ocr_SNws
@@ -235,7 +241,7 @@ def main():
             out["disk_inference"] = disk
         if world == 1 and not args.no_cpu_baseline and args.model == "unet3p":
             out["cpu_baseline"] = cpu_baseline(args.filters, args.size)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
