@@ -1374,3 +1374,48 @@ def test_wide_plain_1x1_conv_gemm_route_matches_conv_kernel(cin, cout, with_bias
     if with_bias:
         assert rel(out[True][3], dy.double().sum((0, 2, 3))) < 1e-4 and rel(out[True][3], out[False][3]) < 1e-5
 
+
+
+@pytest.mark.parametrize("arch", ["unet3p", "unet"])
+def test_models_non_square_ragged_input_vs_oracle(arch):
+    """Whole models on a non-square 48 x 80 input (deepest map 3 x 5: every MFMA / up-sampling / pooling kernel meets
+    partial tiles in both directions), batch 3, n_filters 16.  float32 tier: logits, loss within 1e-3 of the float32
+    oracle.  bf16 tier: logits within 2e-2 (L2) of the oracle with the same bf16 storage points; every gradient finite."""
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from modeling.UNet_SNws import UNet_SNws
+    torch.manual_seed(21)
+    cls = UNet3p_SNws if arch == "unet3p" else UNet_SNws
+    model = cls(14, 16, 10, 1, 1)
+    for p in model.parameters():
+        if p.dim() == 1 and p.numel() == 3:
+            p.data.copy_(torch.randn(3) * 0.5)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    img = bf16_round(torch.rand(3, 14, 48, 80) * 255.0)
+    lab = torch.randint(0, 10, (3, 48, 80)).float()
+    lab[2, 40:] = 255.0
+    logits_ref, loss_ref, _ = O.model_step(arch, {k: v.clone() for k, v in state.items()}, img, lab)
+    logits_r16, _, _ = O.model_step(arch, {k: v.clone() for k, v in state.items()}, img, lab, act_round=torch.bfloat16)
+
+    def l2(a, b):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return float((a - b).norm() / max(float(b.norm()), 1e-12))
+
+    model = model.to(DEV).train()
+    for dtype in (torch.float32, torch.bfloat16):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        model.compute_dtype = dtype
+        logits = model(img.to(DEV))
+        assert tuple(logits.shape) == (3, 10, 48, 80)
+        loss = torch.nn.functional.cross_entropy(logits.float(), lab.to(DEV).long(), ignore_index=255) / 3
+        loss.backward()
+        for name, p in model.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+        if dtype == torch.float32:
+            assert relerr(logits, logits_ref) < 1e-3
+            assert abs(float(loss.detach()) - loss_ref) < 1e-3 * abs(loss_ref)
+        else:
+            noise = l2(logits_r16, logits_ref)
+            print("%s 48x80 bf16: GPU vs bf16-storage oracle %.3g; storage noise %.3g" % (arch, l2(logits, logits_r16), noise))
+            assert l2(logits, logits_r16) < max(2e-2, 0.6 * noise)
+            assert abs(float(loss.detach()) - loss_ref) < 2e-2 * abs(loss_ref)
