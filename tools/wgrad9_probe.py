@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Times snws_conv_mfma_wgrad on the 3x3 shapes of UNet3p_SNws (batch 16, 512^2 input) that carry most of its
+weight-gradient work.  SNWS_WGRAD_BLOCKS=n (read once per process) forces the workgroup count of every launch:
+    for n in 0 512 1024 2048 4096 8192; do SNWS_WGRAD_BLOCKS=$n python tools/wgrad9_probe.py; done"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "semantic-segmentation_amd"))
+import torch
+from snws import _lib as L
+from snws import ops
+
+N = 16
+forced = os.environ.get("SNWS_WGRAD_BLOCKS", "0")
+for cin, cout, S in ((320, 320, 512), (320, 64, 512), (64, 64, 512), (320, 320, 256), (320, 64, 256), (128, 128, 256),
+                     (64, 128, 256), (128, 64, 256), (256, 256, 128), (320, 320, 128), (512, 512, 64), (1024, 1024, 32)):
+    x = torch.randn(N, S, S, cin, device="cuda:0").to(torch.bfloat16)
+    dy = torch.randn(N, S, S, cout, device="cuda:0").to(torch.bfloat16)
+    g = torch.zeros(cout, 3, 3, cin, device="cuda:0")
+    db = torch.zeros(cout, device="cuda:0")
+    cfg = ops.ConvCfg((cout, cin, 3, 3), 1, 1, 1, 1)
+    d = cfg.desc(N, S, S, cin, cin, cout)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run():
+        L.call("snws_conv_mfma_wgrad", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), db.data_ptr(), st)
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 5
+    fl = 2.0 * 9 * N * S * S * cin * cout
+    print("blocks %5s  wgrad 3x3 %4d->%4d @%3d^2: %.3f ms  %6.0f TFLOP/s" % (forced, cin, cout, S, t, fl / t / 1e9), flush=True)
+    del x, dy, g
