@@ -91,7 +91,7 @@ def evaluator_throughput(device, reps=20):
             "frac_of_hbm_peak": 12.0 * npix / sec / 1e9 / HBM_PEAK_GBS, "mIoU": float(ev.Mean_Intersection_over_Union())}
 
 
-def disk_inference(model, device, rank, world, reps=3):
+def disk_inference(model, device, rank, world, reps=3, tiles_per_forward=12):
     """Full-disk inference: one synthetic (14, 2748, 2748) FY-4A disk resident in HBM -> 36 tiles of 512^2 in eval
     mode, arg-max and stitch on the device, Evaluator against a synthetic label map; tiles are dealt round-robin
     to the ranks."""
@@ -100,20 +100,21 @@ def disk_inference(model, device, rank, world, reps=3):
     g = torch.Generator(device="cpu").manual_seed(0)
     disk = (torch.rand((14, 2748, 2748), generator=g) * 255.0).to(device=device, dtype=model.compute_dtype or torch.float32)
     gt = torch.randint(0, 10, (1, 2748, 2748), generator=g).float().to(device)
-    pred = tiles.predict_disk(model, disk, block=512, overlap=0, tiles_per_forward=4)     # warm-up
+    pred = tiles.predict_disk(model, disk, block=512, overlap=0, tiles_per_forward=tiles_per_forward)     # warm-up
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
-        pred = tiles.predict_disk(model, disk, block=512, overlap=0, tiles_per_forward=4)
+        pred = tiles.predict_disk(model, disk, block=512, overlap=0, tiles_per_forward=tiles_per_forward)
         ev = Evaluator(10)
         ev.add_batch(gt, pred[None])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     sec = (time.perf_counter() - t0) / reps
-    return {"workload": "one 14x2748x2748 disk -> 36 tiles of 512x512 (eval), arg-max + stitch + Evaluator on device",
+    return {"workload": "one 14x2748x2748 disk -> 36 tiles of 512x512 (eval, %d tiles per forward), arg-max + stitch + "
+                        "Evaluator on device" % tiles_per_forward,
             "seconds_per_disk": sec, "disks_per_s": 1.0 / sec, "tiles_per_s": 36.0 / sec, "Mpix/s": 2748 * 2748 / sec / 1e6,
             "mIoU_vs_random_labels": float(ev.Mean_Intersection_over_Union())}
 
@@ -130,6 +131,7 @@ def main():
     ap.add_argument("--model", default="unet3p", choices=["unet3p", "unet3p_res_ocr"],
                     help="unet3p = the headline UNet3p_SNws; unet3p_res_ocr = UNet3p_res_ocr_SNws (residual encoder + OCR head)")
     ap.add_argument("--disk", action="store_true", help="also time full-disk tiled inference (36 tiles of 512^2)")
+    ap.add_argument("--disk-tiles", type=int, default=12, help="tiles per forward pass of the full-disk inference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true",
@@ -192,7 +194,7 @@ def main():
         dist.all_reduce(lt)
         loss_val = float(lt)
 
-    disk = disk_inference(model, device, rank, world) if args.disk else None
+    disk = disk_inference(model, device, rank, world, tiles_per_forward=args.disk_tiles) if args.disk else None
     if rank == 0:
         kernels = {}
         for tag, work, e0, e1 in (prof or []):

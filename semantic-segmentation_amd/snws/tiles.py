@@ -32,7 +32,7 @@ def gen_tiles_offs(xsize, ysize, block, overlap):
 
 
 @torch.no_grad()
-def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forward=4, remap_background=False,
+def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forward=12, remap_background=False,
                  group=None, normalize=None):
     """Class map (H, W) int64 of one (C, H, W) disk that already lives on the device.
 
