@@ -177,3 +177,29 @@ print("RESULT " + json.dumps({"losses": losses, "cm": float(ev.confusion_matrix.
     assert grouped["cm"] == plain["cm"] == 2 * 64 * 64 - len(range(0, 2 * 64 * 64, 97)) and grouped["pred"] == plain["pred"]
     for a, b in zip(plain["losses"], grouped["losses"]):
         assert abs(a - b) <= 1e-5 * abs(a)
+
+
+def test_bench_prints_exactly_one_json_line_on_stdout():
+    """The benchmark's contract: stdout is ONE JSON line with the agreed fields, whatever libraries print (RCCL
+    announces its version on stdout when NCCL_DEBUG=VERSION and a communicator is created - exercised here with the
+    one-rank group).  A small configuration keeps it to seconds; the roofline object must still be filled from the
+    3x3 MFMA launches."""
+    import json
+    import subprocess
+    env = dict(os.environ, SNWS_DP_SELFTEST="1", NCCL_DEBUG="VERSION", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--size", "128", "--filters", "32", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 2 * 1000.0 / out["ms_per_step"]) < 1e-6 * out["value"]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["launches"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["traffic"] is None   # traffic: full size only
