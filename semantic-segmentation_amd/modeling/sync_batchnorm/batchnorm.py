@@ -1,35 +1,18 @@
 """SynchronizedBatchNorm{1,2,3}d with the reference's constructor and statistics
 (modeling/sync_batchnorm/batchnorm.py:28-141): per-channel sum and square-sum over (N, spatial), mean = sum/size,
-normalisation with the BIASED variance CLAMPED at eps (not +eps), running buffers updated with the UNBIASED
-variance and PyTorch's momentum convention.
+normalisation with the BIASED variance CLAMPED at eps (not +eps) on the synchronised path, running buffers updated
+with the UNBIASED variance and PyTorch's momentum convention.
 
 Synchronisation: one process per GPU; in training mode under an initialised torch.distributed group the packed
-per-channel moments are all-reduced (RCCL), forward and backward.  4-D GPU inputs (SynchronizedBatchNorm2d) run on
-the library's streaming kernels (snws_sn_stats / snws_bn_* / snws_sn_apply and their backward counterparts) with
-the clamp-at-eps inverse standard deviation in training and evaluation alike; 1-D / 3-D inputs and CPU tensors keep
-the composition of stock torch ops below (outside a process group, or in eval mode, F.batch_norm like the
-reference's fallback, batchnorm.py:40-43).  Only DeepLab-style models use this class (modeling/deeplab.py:16-19)."""
-import torch
+per-channel moments are all-reduced (RCCL), forward and backward.  Every input runs on the library's streaming
+kernels (snws_sn_stats / snws_bn_* / snws_sn_apply and their backward counterparts): (N, C), (N, C, L) and
+(N, C, D, H, W) inputs are viewed as (N, C, positions, 1), one-position-per-sample inputs as one image of N positions.  Outside a process group, and in eval mode, the inverse
+standard deviation is (var + eps)^-1/2 like the reference's F.batch_norm fallback (batchnorm.py:40-43).  There is no
+CPU path: CPU tensors raise.  Only DeepLab-style models use this class (modeling/deeplab.py:16-19)."""
 import torch.distributed as dist
-import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
 __all__ = ['SynchronizedBatchNorm1d', 'SynchronizedBatchNorm2d', 'SynchronizedBatchNorm3d']
-
-
-class _AllReduceSum(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, t, group):
-        ctx.group = group
-        t = t.clone()
-        dist.all_reduce(t, group=group)
-        return t
-
-    @staticmethod
-    def backward(ctx, g):
-        g = g.clone()
-        dist.all_reduce(g, group=ctx.group)
-        return g, None
 
 
 class _SynchronizedBatchNorm(_BatchNorm):
@@ -43,36 +26,26 @@ class _SynchronizedBatchNorm(_BatchNorm):
 
     def forward(self, input):
         self._check_input_dim(input)
-        if input.dim() == 4 and input.is_cuda and self.track_running_stats and self.momentum is not None:
-            from snws import ops
-            if self.training and self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
-            # the reference clamps only on its synchronised path; its fallback is F.batch_norm (var + eps)
-            clamp = self._synced()
-            return ops.BatchNormFn.apply(input, self.weight, self.bias, self.running_mean, self.running_var,
-                                         self.momentum, self.eps, self.training, False, True, self.process_group, clamp)
-        if not self._synced():
-            return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, self.training,
-                                self.momentum, self.eps)
-        shape = input.size()
-        x = input.reshape(shape[0], self.num_features, -1)
-        local = torch.cat([x.sum((0, 2)), (x * x).sum((0, 2)),
-                           x.new_tensor([float(x.size(0) * x.size(2))])])
-        total = _AllReduceSum.apply(local, self.process_group)
-        C = self.num_features
-        size = total[2 * C].detach()
-        assert float(size) > 1, 'BatchNorm computes unbiased standard-deviation, which requires size > 1.'
-        mean = total[:C] / size
-        sumvar = total[C:2 * C] - total[:C] * mean
-        with torch.no_grad():
-            self.running_mean.mul_(1 - self.momentum).add_(self.momentum * mean)
-            self.running_var.mul_(1 - self.momentum).add_(self.momentum * sumvar / (size - 1))
-        inv_std = (sumvar / size).clamp(self.eps) ** -0.5
-        if self.affine:
-            y = (x - mean.view(1, C, 1)) * (inv_std * self.weight).view(1, C, 1) + self.bias.view(1, C, 1)
+        from snws import ops
+        ops.require_gpu(input, type(self).__name__)
+        if self.momentum is None:
+            raise ValueError("%s: momentum=None (cumulative average) is not supported" % type(self).__name__)
+        shape, C = input.shape, self.num_features
+        per_sample = input.numel() // max(shape[0] * C, 1)
+        if input.dim() == 4:
+            x = input
+        elif per_sample == 1:     # (N, C) or (N, C, 1): the batch axis becomes the pixel axis of ONE image - the kernels
+            x = input.reshape(shape[0], C).t().reshape(1, C, shape[0], 1)    # take per-image moments over >= 2 positions
         else:
-            y = (x - mean.view(1, C, 1)) * inv_std.view(1, C, 1)
-        return y.view(shape)
+            x = input.reshape(shape[0], C, -1, 1)
+        if self.training and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        # the reference clamps only on its synchronised path; its fallback is F.batch_norm (var + eps)
+        y = ops.BatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
+                                  self.eps, self.training, False, True, self.process_group, self._synced())
+        if input.dim() == 4:
+            return y
+        return y.reshape(C, shape[0]).t().reshape(shape) if per_sample == 1 else y.reshape(shape)
 
 
 class SynchronizedBatchNorm1d(_SynchronizedBatchNorm):

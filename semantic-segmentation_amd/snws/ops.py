@@ -620,6 +620,10 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
     xs, ldx = as_nhwc(x)
     ctx = torch.empty(lib.snws_sn_ctx_floats(N, C), dtype=torch.float32, device=dev)
     use_batch = training or running_mean is None
+    if use_batch and HW < 2:
+        # the moment kernels work per image with the unbiased (HW - 1) divisor in between
+        raise ValueError("BatchNorm2d: batch statistics need at least 2 positions per image (got %dx%d); "
+                         "present single-position samples as one image of N positions" % (H, W))
     synced = bool(sync and use_batch and dp_collectives(group))
     world = sync_world(group) if synced else 1
     pack = None

@@ -1419,3 +1419,38 @@ def test_models_non_square_ragged_input_vs_oracle(arch):
             print("%s 48x80 bf16: GPU vs bf16-storage oracle %.3g; storage noise %.3g" % (arch, l2(logits, logits_r16), noise))
             assert l2(logits, logits_r16) < max(2e-2, 0.6 * noise)
             assert abs(float(loss.detach()) - loss_ref) < 2e-2 * abs(loss_ref)
+
+
+@pytest.mark.parametrize("dims,shape", [(1, (6, 10)), (1, (4, 10, 7)), (2, (3, 10, 5, 6)), (3, (2, 10, 3, 4, 5))])
+def test_synchronized_batchnorm_all_ranks_vs_torch(dims, shape):
+    """SynchronizedBatchNorm{1,2,3}d outside a process group == nn.BatchNorm{1,2,3}d (the reference's fallback,
+    modeling/sync_batchnorm/batchnorm.py:40-43) on the HIP kernels for every input rank: output, gradients, running
+    buffers after two training calls, eval output."""
+    import modeling.sync_batchnorm as sb
+    torch.manual_seed(13)
+    C = shape[1]
+    ref = {1: torch.nn.BatchNorm1d, 2: torch.nn.BatchNorm2d, 3: torch.nn.BatchNorm3d}[dims](C).double()
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(C) + 0.5)
+        ref.bias.copy_(torch.randn(C) * 0.3)
+    m = {1: sb.SynchronizedBatchNorm1d, 2: sb.SynchronizedBatchNorm2d, 3: sb.SynchronizedBatchNorm3d}[dims](C).to(DEV)
+    m.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    x = torch.randn(shape) * 1.7 + 0.4
+    dy = torch.randn(shape)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    y = m(xg)
+    assert tuple(y.shape) == tuple(shape)
+    y.backward(dy.to(DEV))
+    assert relerr(y, yr) < 1e-4 and relerr(xg.grad, xr.grad) < 1e-4
+    assert relerr(m.weight.grad, ref.weight.grad) < 1e-4 and relerr(m.bias.grad, ref.bias.grad) < 1e-4
+    with torch.no_grad():
+        ref(xr.detach() * 1.5 - 0.2)
+        m(xg.detach() * 1.5 - 0.2)
+    assert relerr(m.running_mean, ref.running_mean) < 1e-4 and relerr(m.running_var, ref.running_var) < 1e-4
+    assert int(m.num_batches_tracked) == 2
+    ref.eval(); m.eval()
+    with torch.no_grad():
+        assert relerr(m(xg.detach()), ref(xr.detach())) < 1e-4
