@@ -10,7 +10,8 @@ LR, i.e. Trainer.training's inner loop.  Inputs are resident in HBM before the t
 line.  `roofline` is for the dominant kernel (the 3x3 MFMA implicit-GEMM kernel conv_fwd_kernel<32,9,...> that runs
 forward and dgrad, in both of its epilogue variants): algorithmic FLOPs of its launches / their HIP-event durations
 inside the timed region, against the dense bf16 MFMA peak.  (`kernels` lists the variants separately:
-conv_mfma_dgradsn_* are the dgrad launches whose epilogue also runs the SwitchNorm backward reduction.)
+conv_mfma_dgradsn_* are the dgrad launches whose epilogue also runs the SwitchNorm backward reduction; sn_apply /
+sn_bwd_apply are the HBM-bound SwitchNorm streaming passes, in GB/s of their algorithmic 2 / 3 tensor passes.)
 `cpu_baseline` times the CPU oracle (a port of the reference's arithmetic) on rank 0's host cores on a bounded
 sample of the same workload.
 """
@@ -136,7 +137,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="bracket EVERY kernel launch with HIP events (fills the `kernels` table; costs ~5 ms of host "
-                         "time per step); default: only the roofline kernel's launches")
+                         "time per step); default: the roofline kernel's launches and the SwitchNorm apply passes")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON result: whatever libraries print there (RCCL announces its version
@@ -176,8 +177,9 @@ def main():
         loss = trainer.step(img, lab)
     barrier()
     ops.PROFILE = None if args.no_kernel_events else []
+    # default: the roofline kernel's launches plus the two SwitchNorm streaming passes (HBM-bound: GB/s in `kernels`)
     ops.PROFILE_ONLY = None if args.all_kernel_events else ("conv_mfma_fwd_k3_kc32", "conv_mfma_dgrad_k3_kc32",
-                                                            "conv_mfma_dgradsn_k3_kc32")
+                                                            "conv_mfma_dgradsn_k3_kc32", "sn_apply", "sn_bwd_apply")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(img, lab)
