@@ -51,6 +51,8 @@ out += ["", "Other files:", "",
         "two `rocprofv3 --pmc` runs, FETCH_SIZE and WRITE_SIZE, no tracing beside `--kernel-trace`; FETCH_SIZE doubled as gfx950 "
         "tallies 128-byte requests at 64 bytes); `bench.py` copies it into `roofline.traffic`.",
         "* `r01_pmc_bench_all_kernels.json` - the same two passes for EVERY kernel of the step (table below).",
+        "* `r01_pmc_sq_conv_wgrad.txt` - SQ / GRBM counter passes (`tools/run_pmc.sh conv|wgrad`) of the 320->320 3x3 layer at 512x512: "
+        "MFMA pipe busy 69 % (forward) / 61 % (wgrad) of active cycles at an effective clock of 1.86 / 1.77 GHz.",
         "* `r01_res_ocr_bs16_512_kernel_stats.csv`, `r01_bench_res_ocr_gpus1.json` - `bench.py --model unet3p_res_ocr` "
         "(UNet3p_res_ocr_SNws, batch 16, 512x512): kernel summary and JSON line.",
         "* `r01_bench_disk_gpus1.json` - `bench.py --disk`: adds full-disk tiled inference (36 tiles of one 2748x2748 disk)."]
