@@ -345,7 +345,12 @@ def test_switchnorm_f32_golden(pre):
 
 @pytest.mark.parametrize("shape,dtype,tol", [((2, 64, 32, 32), torch.bfloat16, 2e-2), ((3, 320, 16, 16), torch.bfloat16, 2e-2),
                                              ((2, 64, 32, 32), torch.float32, 1e-3), ((2, 1024, 8, 8), torch.bfloat16, 2e-2),
-                                             ((2, 24, 9, 7), torch.bfloat16, 2e-2)])
+                                             ((2, 24, 9, 7), torch.bfloat16, 2e-2),
+                                             ((1, 16, 12, 12), torch.bfloat16, 2e-2),      # a batch of one image
+                                             ((2, 10, 9, 7), torch.bfloat16, 2e-2),        # channels not a multiple of 8: scalar lanes
+                                             ((3, 5, 6, 11), torch.float32, 1e-3),
+                                             ((1, 8, 300, 300), torch.float32, 1e-3),      # many tiles per plane
+                                             ((16, 64, 128, 128), torch.bfloat16, 2e-2)])  # the benchmark's batch
 def test_switchnorm_relu_vs_oracle(shape, dtype, tol):
     import modeling.snorm as sn
     torch.manual_seed(2)
@@ -369,9 +374,17 @@ def test_switchnorm_relu_vs_oracle(shape, dtype, tol):
     dxr, dgr, dbr, dmwr, dvwr = O.switchnorm_bwd(dy.double(), st, ctx)
     assert y.dtype == dtype
     assert relerr(y.float(), yr) < tol
-    assert relerr(xg.grad.float(), dxr) < tol
-    assert relerr(m.weight.grad.view(-1), dgr) < tol and relerr(m.bias.grad.view(-1), dbr) < tol
-    assert relerr(m.mean_weight.grad, dmwr) < 2 * tol and relerr(m.var_weight.grad, dvwr) < 2 * tol
+    # The ReLU mask is recomputed from the pre-activation: where that is zero to rounding (a handful of the elements of
+    # a large tensor) the two implementations may legitimately disagree on the mask, and dx then differs by the whole
+    # A * dy term there.  Every deviating element must be such a tie (output ~ 0 on both sides), and they must be rare.
+    dxg = xg.grad.detach().double().cpu()
+    bad = (dxg - dxr).abs() > tol * dxr.abs().max()
+    ymax = float(yr.abs().max())
+    assert int(bad.sum()) <= max(2, int(2e-5 * bad.numel())), int(bad.sum())
+    assert bool((y.detach().double().cpu()[bad].abs() <= 2e-5 * ymax).all()) and bool((yr[bad].abs() <= 2e-5 * ymax).all())
+    ptol = tol + (5e-3 if bool(bad.any()) else 0.0)      # a flipped tie moves the parameter sums by that element's dy
+    assert relerr(m.weight.grad.view(-1), dgr) < ptol and relerr(m.bias.grad.view(-1), dbr) < ptol
+    assert relerr(m.mean_weight.grad, dmwr) < 2 * ptol and relerr(m.var_weight.grad, dvwr) < 2 * ptol
     assert relerr(m.running_mean.view(-1), st.running_mean) < 1e-4
     assert relerr(m.running_var.view(-1), st.running_var) < 1e-3
 
