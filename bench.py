@@ -2,7 +2,7 @@
 """Headline benchmark: train images/sec of UNet3p_SNws (14 bands -> 10 classes, n_filters 64) at 512x512 in bf16,
 batch 16 per GPU, synthetic FY-4A-shaped tiles, data-parallel over N GPUs of one node (one process per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = zero_grad -> forward -> CE/N loss -> backward -> (bucketed gradient all-reduce) -> AdamW step with the poly
@@ -139,6 +139,12 @@ def main():
                     help="bracket EVERY kernel launch with HIP events (fills the `kernels` table; costs ~5 ms of host "
                          "time per step); default: the roofline kernel's launches and the SwitchNorm apply passes")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as children of this process, BEFORE
+    # anything here touches the GPU, and relay rank 0's result line (train.py:210-214 needs no launcher either)
+    from snws import launch
+    if args.gpus > 1 and not launch.launched():
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     # stdout carries exactly one line, the JSON result: whatever libraries print there (RCCL announces its version
     # on stdout when a communicator is created) is sent to stderr instead, on every rank

@@ -46,18 +46,19 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ lo
 #pragma unroll
     for (int c = 0; c < CE_MAX_C; ++c)
       if (c < C) m = fmaxf(m, v[c]);
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CE_MAX_C; ++c)
-      if (c < C) { v[c] = __expf(v[c] - m); s += v[c]; }
     const float tf = target[p];
     const int t = (int)tf;                       // .long(): truncation toward zero
     const bool valid = t != ignore_index;
-    float picked = 0.f;
+    float s = 0.f, gap = 0.f;                    // gap = logit[t] - max, taken BEFORE exponentiating: exp(gap) may underflow
 #pragma unroll
     for (int c = 0; c < CE_MAX_C; ++c)
-      if (c < C && c == t) picked = v[c];
-    if (valid) acc += -__logf(picked / s);        // = logsumexp - logit[t]
+      if (c < C) {
+        const float d = v[c] - m;
+        if (c == t) gap = d;
+        v[c] = __expf(d);
+        s += v[c];
+      }
+    if (valid) acc += __logf(s) - gap;            // = logsumexp - logit[t], finite for any finite logits
     if (dlogits) {
       const float k = valid ? scale / s : 0.f;
       T* drow = dlogits + p * ldd;

@@ -60,12 +60,15 @@ class ConvSnRelu(nn.Sequential):
 
 
 def crop_concat(a, b):
-    """Centre-crop skip `a` to b's spatial size (diff//2 from the top/left) and stack (a, b) on the channel axis
-    (CropConcat, modeling/UNet_SNws.py:35-39)."""
+    """Fit skip `a` to b's spatial size and stack (a, b) on the channel axis (CropConcat, modeling/UNet_SNws.py:35-39:
+    F.pad with the negated size differences).  Where `a` is larger it is centre-cropped (diff//2 from the top/left);
+    where it is SMALLER - a ceil-mode pool followed by the x2 up-sampling leaves the decoder map one pixel larger than
+    the skip on odd sizes, e.g. 75 -> 38 -> 76 - it is zero-padded by the same rule (Python floor division: -1//2 = -1,
+    so the single extra row/column goes to the top/left)."""
     dy = a.size(2) - b.size(2)
     dx = a.size(3) - b.size(3)
     if dy or dx:
-        a = a[:, :, dy // 2: a.size(2) - (dy - dy // 2), dx // 2: a.size(3) - (dx - dx // 2)]
+        a = torch.nn.functional.pad(a, (-(dx // 2), -(dx - dx // 2), -(dy // 2), -(dy - dy // 2)))
     return torch.cat((a, b), dim=1)
 
 

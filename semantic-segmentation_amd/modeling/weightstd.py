@@ -20,16 +20,17 @@ class Conv2dws(nn.Conv2d):
         self._taps = None
         self._taps_key = None
         self.force_direct = False   # True pins the exact direct kernels (float32 tier / debugging)
+        self.cache_filters = False  # a training driver that announces weight updates switches this on (snws.ops)
 
     def prepared(self, want_mfma):
         """Standardized filter images.  Rebuilt on every call, like the reference, unless a training driver has
-        switched on snws.ops.CACHE_FILTERS and announces weight updates with snws.ops.weights_changed(); then a
-        module shared by several call sites in one forward standardizes once per step."""
+        switched on this module's cache_filters and announces weight updates with snws.ops.weights_changed(); then
+        a module shared by several call sites in one forward standardizes once per step."""
         w = self.weight
-        key = ops.filter_cache_key(w, want_mfma)
+        key = ops.filter_cache_key(w, want_mfma, self.cache_filters)
         if self._prep is None or key is None or self._prep_key != key:
             cfg = ops.ConvCfg(w.shape, self.stride, self.padding, self.dilation, self.groups)
-            self._prep = ops.PreparedWeight(w, cfg, want_mfma, reuse=self._prep if ops.CACHE_FILTERS else None)
+            self._prep = ops.PreparedWeight(w, cfg, want_mfma, reuse=self._prep if self.cache_filters else None)
             self._prep_key = key
         return self._prep
 
@@ -37,7 +38,7 @@ class Conv2dws(nn.Conv2d):
         """The standardized filter re-laid as a (kh*kw*O, I, 1, 1) filter for conv-of-an-up-sampled-map
         (snws.ops.TapConvFn); cached per weight version like prepared()."""
         w = self.weight
-        key = ops.filter_cache_key(w, want_mfma)
+        key = ops.filter_cache_key(w, want_mfma, self.cache_filters)
         if self._taps is None or key is None or self._taps_key != key:
             cfg = ops.ConvCfg(w.shape, self.stride, self.padding, self.dilation, self.groups)
             if cfg.stride != 1 or cfg.dil != 1 or cfg.groups != 1 or cfg.kh != cfg.kw or cfg.kh not in (1, 3) or \

@@ -26,7 +26,10 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("SNWS_DP_SHARE_GPU") == "1"     # rehearsal: every rank on GPU 0, collectives over gloo
     if torch.cuda.is_available():
+        if share:
+            local = 0
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -35,7 +38,7 @@ def init_distributed():
     if (world > 1 or os.environ.get("SNWS_DP_SELFTEST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = "nccl" if torch.cuda.is_available() and not share else "gloo"
         kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, device
@@ -62,12 +65,8 @@ def global_ce_loss(logits, target, ignore_index=255, group=None):
     cnt = torch.stack([(t != ignore_index).sum().to(torch.float32),
                        torch.full((), float(n), dtype=torch.float32, device=logits.device)])
     if _dp(group):
-        if cnt.is_cuda and dist.get_backend(group) == "gloo":
-            h = cnt.cpu()
-            dist.all_reduce(h, group=group)
-            cnt = h.to(cnt.device)
-        else:
-            dist.all_reduce(cnt, group=group)
+        from . import ops
+        ops.all_reduce(cnt, "sum", group)
     return ce_sum / cnt[0] / cnt[1]
 
 
@@ -81,12 +80,7 @@ def global_ce_loss_fused(raw_logits, n_class, target, ignore_index=255, group=No
     cnt = torch.stack([(target.to(torch.int64) != ignore_index).sum().to(torch.float32),
                        torch.full((), float(n), dtype=torch.float32, device=raw_logits.device)])
     if _dp(group):
-        if cnt.is_cuda and dist.get_backend(group) == "gloo":
-            h = cnt.cpu()
-            dist.all_reduce(h, group=group)
-            cnt = h.to(cnt.device)
-        else:
-            dist.all_reduce(cnt, group=group)
+        ops.all_reduce(cnt, "sum", group)
     scale = 1.0 / (cnt[0] * cnt[1])
     return ops.FusedCEFn.apply(raw_logits, target, n_class, scale, ignore_index)
 
@@ -146,26 +140,14 @@ class GradBuckets:
             lo, hi = self.slices[bi]
             flat = self.flat_grad[lo:hi]
             ops.trace_collective("bucket%d" % bi, flat.numel())
-            if flat.is_cuda and dist.get_backend(self.group) == "gloo":
-                host = flat.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                flat.copy_(host)
-                return
-            self.work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, ()))
+            self.work.append((ops.all_reduce(flat, "sum", self.group, async_op=True), None, ()))
             return
         ps = [p for p in self.buckets[bi] if p.grad is not None]
         if not ps:
             return
         flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
         ops.trace_collective("bucket%d" % bi, flat.numel())
-        if flat.is_cuda and dist.get_backend(self.group) == "gloo":   # test vehicle: reduce on the host, synchronously
-            host = flat.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-            flat.copy_(host)
-            self.work.append((None, flat, ps))
-            return
-        h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.work.append((h, flat, ps))
+        self.work.append((ops.all_reduce(flat, "sum", self.group, async_op=True), flat, ps))
 
     def _hook(self, p):
         bi = self.where[p]
@@ -215,8 +197,15 @@ class Trainer:
             self.buckets = GradBuckets(list(model.parameters()), bucket_mb, group)
         self.it = 0
         from . import ops
-        ops.CACHE_FILTERS = True        # this driver owns the weights: it announces every update below
+        # this driver owns the weights of ITS model and announces every update below: the model's Conv2dws modules
+        # may keep their standardized filters between calls (modules of other models are not affected)
+        ops.set_filter_cache(model, True)
         ops.weights_changed()
+
+    def close(self):
+        """Give the model back: its Conv2dws modules standardize on every call again, like the reference."""
+        from . import ops
+        ops.set_filter_cache(self.model, False)
 
     def step(self, image, target):
         """train.py:246-255.  Returns this rank's share of the global loss (a 0-d tensor; no host sync)."""

@@ -20,11 +20,12 @@ PROFILE = None
 
 
 # Standardized-filter cache control.  By default a Conv2dws standardizes its filter on every call, exactly like the
-# reference.  A training driver that knows when weights change (snws.harness.Trainer) sets CACHE_FILTERS = True and
-# calls weights_changed() after every optimizer step / state_dict load; then a module shared by several call sites
-# standardizes once per step.  (Tensor version counters are not a safe key: fused optimizers update in place
-# without bumping them.)
-CACHE_FILTERS = False
+# reference.  A training driver that knows when weights change (snws.harness.Trainer) switches the cache on for the
+# Conv2dws modules of ITS model (module.cache_filters = True) and every weight update is announced with
+# weights_changed() - the Trainer after its optimizer step, FlatAdamW.step / load_state_dict and
+# checkpoint.load_checkpoint by themselves; then a module shared by several call sites standardizes once per step.
+# (Tensor version counters are not a safe key on their own: fused optimizers update in place without bumping them.)
+# Modules outside such a driver never cache, whatever other drivers exist in the process.
 WEIGHT_EPOCH = 0
 
 
@@ -33,8 +34,17 @@ def weights_changed():
     WEIGHT_EPOCH += 1
 
 
-def filter_cache_key(w, want_mfma):
-    return (WEIGHT_EPOCH, w._version, w.data_ptr(), str(w.device), bool(want_mfma)) if CACHE_FILTERS else None
+def filter_cache_key(w, want_mfma, enabled):
+    return (WEIGHT_EPOCH, w._version, w.data_ptr(), str(w.device), bool(want_mfma)) if enabled else None
+
+
+def set_filter_cache(model, enabled):
+    """Switch the standardized-filter cache of every Conv2dws under `model` on or off."""
+    for m in model.modules():
+        if hasattr(m, "cache_filters"):
+            m.cache_filters = bool(enabled)
+            if not enabled:
+                m._prep = m._prep_key = m._taps = m._taps_key = None
 
 
 def _stream():
@@ -215,7 +225,7 @@ class PreparedWeight:
 
     def __init__(self, weight, cfg, want_mfma, standardize=True, reuse=None):
         """reuse: the PreparedWeight of the previous weight version, whose buffers are overwritten in place (only a
-        driver that owns the step structure, i.e. CACHE_FILTERS, may pass it: no graph may still need the old images)."""
+        driver that owns the step structure, i.e. one that switched the module's cache_filters on, may pass it: no graph may still need the old images)."""
         require_gpu(weight, "Conv2dws")
         self.standardize = standardize
         w = weight.detach()
@@ -429,17 +439,59 @@ def _conv_backward_weights(dys, lddy, prep, saved, weight, need_dw, need_db, bia
 
 
 # ------------------------------------------------------------------------------------------------ SwitchNorm
-def _allreduce_sum(t, group):
+_REDUCE_OPS = {"sum": "SUM", "max": "MAX"}
+
+
+def all_reduce(t, op="sum", group=None, async_op=False):
+    """In-place all-reduce of t over `group`.  RCCL takes the device tensor directly; gloo - only the CPU / shared-GPU
+    test vehicle - gets device tensors staged through the host explicitly (its own device-tensor path stalls when
+    ranks share one GPU) and is then always synchronous.  Returns the work handle of an asynchronous call, else None."""
     import torch.distributed as dist
-    trace_collective("sn", t.numel())
+    rop = getattr(dist.ReduceOp, _REDUCE_OPS[op])
     if t.is_cuda and dist.get_backend(group) == "gloo":
-        # gloo is only the single-GPU / CPU test vehicle: stage the few hundred bytes through the host explicitly
-        # (its own device-tensor path stalls when ranks share one GPU); RCCL takes the device tensor directly
         h = t.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(h, op=rop, group=group)
+        t.copy_(h)
+        return None
+    w = dist.all_reduce(t, op=rop, group=group, async_op=async_op)
+    return w if async_op else None
+
+
+def broadcast(t, src=0, group=None):
+    """In-place broadcast with the same gloo staging rule as all_reduce."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.broadcast(h, src, group=group)
         t.copy_(h)
         return
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    dist.broadcast(t, src, group=group)
+
+
+# The SwitchNorm / BatchNorm statistic all-reduces (a few KB each, one per normalisation call and direction) get a
+# process group of their own: under RCCL that is a separate communicator with its own stream, so a statistic
+# all-reduce issued in backward never queues behind a 25 MB gradient bucket that is in flight on the default group.
+# SNWS_STAT_GROUP=0 keeps them on the default group.
+_STAT_GROUP = {}
+
+
+def stat_group(group=None):
+    """The process group the statistic all-reduces of `group` (None = the default group) run on.  Created on first
+    use; every rank reaches its first normalisation call of a step at the same point, so the collective creation
+    call is matched on all ranks."""
+    import torch.distributed as dist
+    if group is not None or os.environ.get("SNWS_STAT_GROUP", "1") == "0":
+        return group
+    key = id(dist.group.WORLD)
+    g = _STAT_GROUP.get(key)
+    if g is None:
+        g = _STAT_GROUP[key] = dist.new_group(backend=dist.get_backend())
+    return g
+
+
+def _allreduce_sum(t, group):
+    trace_collective("sn", t.numel())
+    all_reduce(t, "sum", stat_group(group))
 
 
 def trace_collective(kind, numel):

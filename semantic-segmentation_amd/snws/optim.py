@@ -100,6 +100,8 @@ class FlatAdamW:
             L.call("snws_adamw_step", self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
                    self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, float(g["lr"]),
                    float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), int(step), float(grad_scale), st)
+        # the raw kernel does not bump tensor version counters: tell the standardized-filter caches
+        ops.weights_changed()
 
     def state_dict(self):
         state = {}
@@ -135,3 +137,4 @@ class FlatAdamW:
             self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
             self.steps[pos] = int(float(st["step"]))
+        ops.weights_changed()

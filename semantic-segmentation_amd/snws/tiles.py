@@ -83,11 +83,6 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
         if raw:
             model.raw_logits = False
     if merge:
-        if dist.get_backend(group) == "gloo":     # CPU-side test vehicle: stage through host memory
-            h = pred.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
-            pred = h.to(pred.device)
-        else:
-            dist.all_reduce(pred, op=dist.ReduceOp.MAX, group=group)
+        ops.all_reduce(pred, "max", group)
         pred = pred & 255
     return pred

@@ -47,6 +47,7 @@ class Evaluator(object):
         self.num_class = num_class
         self.confusion_matrix = np.zeros((self.num_class,) * 2)
         self._counts = None     # device int64 [C*C + 2], pending counts not yet folded into confusion_matrix
+        self._local = np.zeros((self.num_class,) * 2)   # counts of THIS rank folded since the last all-reduce
 
     # ---- metrics: the reference's expressions, verbatim semantics (metrics.py:9-38)
     def Pixel_Accuracy(self):
@@ -78,25 +79,34 @@ class Evaluator(object):
 
     def sync(self, group=None, all_reduce=False):
         """Fold the device-side counts into `confusion_matrix` (one small D2H copy).  With all_reduce=True the
-        counts are first summed over the data-parallel ranks (one 8*(C*C+2)-byte all-reduce)."""
-        if self._counts is None:
+        counts are first summed over the data-parallel ranks (one 8*(C*C+2)-byte all-reduce); a rank with nothing
+        pending - an empty validation shard, counts already folded by a metric call or a numpy add_batch - still
+        takes part, with zeros, so the collective is matched on every rank."""
+        from snws import ops
+        reduce_now = bool(all_reduce) and ops.dp_collectives(group)
+        if self._counts is None and not reduce_now:
             return
         c = self._counts
-        if all_reduce:
-            import torch.distributed as dist
-            from snws import ops
-            if ops.dp_collectives(group):
-                if dist.get_backend(group) == "gloo":
-                    c = c.cpu()
-                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        C2 = self.num_class * self.num_class
+        if reduce_now:
+            if c is None:
+                c = torch.zeros(C2 + 2, dtype=torch.int64, device=_device())
+            # what this rank folded locally since the last reduction (metric calls, numpy add_batch) joins the sum too
+            c[:C2] += torch.from_numpy(self._local.reshape(-1).astype(np.int64)).to(c.device)
+            ops.all_reduce(c, "sum", group)
         host = c.cpu().numpy()
         self._counts = None
-        C2 = self.num_class * self.num_class
         if host[C2] or host[C2 + 1]:
             # the reference's bincount/reshape raises for a prediction outside the matrix (metrics.py:42-44)
             raise ValueError("Evaluator.add_batch: %d prediction(s) outside [0, num_class) for a valid label"
                              % int(host[C2] + host[C2 + 1]))
-        self.confusion_matrix += host[:C2].reshape(self.num_class, self.num_class)
+        add = host[:C2].reshape(self.num_class, self.num_class)
+        if reduce_now:
+            self.confusion_matrix += add - self._local      # the local part is already in the matrix
+            self._local = np.zeros_like(self._local)
+        else:
+            self.confusion_matrix += add
+            self._local += add
 
     def _matrix(self):
         self.sync()
@@ -137,4 +147,5 @@ class Evaluator(object):
 
     def reset(self):
         self._counts = None
+        self._local = np.zeros((self.num_class,) * 2)
         self.confusion_matrix = np.zeros((self.num_class,) * 2)

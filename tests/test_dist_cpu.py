@@ -170,3 +170,36 @@ def test_global_loss_and_gradient_buckets():
 def test_data_parallel_model_step_equals_reference_full_batch():
     res = _run(_w_model)
     assert all(r[1] for r in res), res
+
+
+def test_self_launcher_starts_ranks_and_relays_one_result_line(tmp_path):
+    """snws.launch.spawn_ranks - what `python bench.py --gpus N` uses when no launcher started it: N ranks come up as
+    children with RANK / WORLD_SIZE / MASTER_* set, rank 0's JSON line is relayed (and nothing else), and a failing
+    rank makes the call return non-zero."""
+    import io
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "semantic-segmentation_amd"))
+    from snws import launch
+    script = tmp_path / "ranks.py"
+    script.write_text(
+        "import os, sys, json\n"
+        "import torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(os.environ['RANK']) + 1.0])\n"
+        "dist.all_reduce(t)\n"
+        "print('noise from rank', os.environ['RANK'])\n"
+        "if '--fail' in sys.argv and dist.get_rank() == 1:\n"
+        "    sys.exit(3)\n"
+        "if dist.get_rank() == 0:\n"
+        "    print(json.dumps({'sum': float(t), 'world': dist.get_world_size(), 'argv': sys.argv[1:]}))\n"
+        "dist.destroy_process_group()\n")
+    assert not launch.launched()
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.spawn_ranks(str(script), ["--steps", "3"], 2, out=out, err=err)
+    assert rc == 0, err.getvalue()[-2000:]
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"sum": 3.0, "world": 2, "argv": ["--steps", "3"]}
+    assert "noise from rank" in err.getvalue()
+    out, err = io.StringIO(), io.StringIO()
+    assert launch.spawn_ranks(str(script), ["--fail"], 2, out=out, err=err) != 0

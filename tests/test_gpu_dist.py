@@ -132,6 +132,99 @@ def test_two_rank_step_equals_reference_full_batch():
         assert errs["cm_equal"] and errs["disk_equal"] and errs["fused_loss"] < 1e-5 and errs["syncbn"] < 1e-4
 
 
+def _worker_trainer(rank, world, port, q, trace_dir):
+    """Full Trainer.step with the flat optimizer (flat in-place gradient buckets, gradient sinks, in-kernel
+    accumulation for the shared decoder blocks) on one image per rank; then, with the process group gone, the same
+    step on the full batch in this process alone."""
+    for p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd"), G):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      SNWS_TRACE_COLLECTIVES=trace_dir)
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import patterns
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from snws import harness
+    from utils.metrics import Evaluator
+    g = np.load(os.path.join(G, "g4_unet3p.npz"))
+    dev = torch.device("cuda", 0)
+    img, lab = patterns.synth_batch(2, 14, 64, 101)
+
+    def one_step(images, labels):
+        model = UNet3p_SNws(14, 4, 10, 1, 1)
+        patterns.det_init(model)
+        model = model.to(dev)
+        tr = harness.Trainer(model, total_iters=50, bucket_mb=0.05)
+        assert type(tr.opt).__name__ == "FlatAdamW" and tr.buckets.slices is not None
+        tr.opt.param_groups[0]["eps"] = 1e-3    # the first AdamW update is lr * g / (|g| + eps): keep it smooth in g
+        loss = tr.step(images.to(dev), labels.to(dev))
+        grads = {n: tr.opt.flat_g[o:o + p.numel()].view(p.shape).detach().cpu().numpy().copy()
+                 for (n, p), o in zip([(n, p) for n, p in model.named_parameters() if p.requires_grad], tr.opt.offsets)}
+        params = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+        bufs = {n: b.detach().cpu().numpy().copy() for n, b in model.named_buffers()}
+        return float(loss), grads, params, bufs, len(tr.buckets.buckets), tr
+
+    loss, grads, params, bufs, nb, tr = one_step(img[rank:rank + 1], lab[rank:rank + 1])
+    tot = torch.tensor([loss])
+    dist.all_reduce(tot)
+    errs = {"loss": abs(float(tot) - float(g["loss"])) / float(g["loss"])}
+    errs["grads"] = max(float(np.abs(v - g["grad:" + n]).max() / max(np.abs(g["grad:" + n]).max(), 1e-6))
+                        for n, v in grads.items())
+    errs["buffers"] = max(float(np.abs(v - g["buf:" + n]).max() / max(np.abs(g["buf:" + n]).max(), 1e-6))
+                          for n, v in bufs.items())
+    # Evaluator.sync(all_reduce=True) on a rank with nothing pending (rank 1 counts nothing) and with counts already
+    # folded by a metric call (rank 0): every rank must take part and every rank must end with the global matrix
+    ev = Evaluator(10)
+    pred = torch.from_numpy(np.argmax(g["logits"], axis=1))
+    if rank == 0:
+        ev.add_batch(lab[:1].to(dev), pred[:1].to(dev))
+        ev.Pixel_Accuracy()                      # folds the pending counts locally
+        ev.add_batch(lab[1:].to(dev), pred[1:].to(dev))
+    ev.sync(all_reduce=True)
+    from oracle import snws_oracle as O
+    errs["cm_equal"] = bool(np.array_equal(ev.confusion_matrix,
+                                           O.confusion_matrix(lab.numpy(), pred.numpy(), 10).astype(np.float64)))
+    dist.barrier()
+    dist.destroy_process_group()
+    # the same step on the full batch, one process, no collectives
+    os.environ.pop("SNWS_TRACE_COLLECTIVES")
+    tr.close()
+    loss1, grads1, params1, bufs1, _, _ = one_step(img, lab)
+    errs["loss_vs_single"] = abs(float(tot) - loss1) / abs(loss1)
+    errs["params"] = max(float(np.abs(v - params1[n]).max()) for n, v in params.items())
+    q.put((rank, errs, nb))
+
+
+def test_two_rank_flat_trainer_step_equals_full_batch_step(tmp_path):
+    """The path bench.py really runs under data parallelism - Trainer.step with FlatAdamW: backward kernels writing
+    into the flat gradient, in-place bucket all-reduces on its slices, the fused optimizer - with two ranks, one
+    image each: summed loss, reduced gradients and running buffers must equal the reference's full-batch fixture
+    (float32 tier) and the post-step parameters those of a single-process step on the full batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_trainer, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, errs, nb in res:
+        print(rank, errs, nb)
+        assert nb >= 2
+        assert errs["loss"] < 1e-3 and errs["grads"] < 3e-3 and errs["buffers"] < 1e-3 and errs["cm_equal"]
+        assert errs["loss_vs_single"] < 1e-5 and errs["params"] < 2e-5
+    # both ranks issued the same collectives in the same order
+    logs = [open(os.path.join(str(tmp_path), "coll_rank%d.log" % r)).read().split("\n") for r in range(2)]
+    assert logs[0] == logs[1] and len(logs[0]) > 10
+    n_sn = sum(1 for ln in logs[0] if ln.startswith("sn "))
+    print("statistic all-reduces per step:", n_sn)
+    assert n_sn <= 68
+
+
 def test_rccl_path_with_one_rank_group():
     """SNWS_DP_SELFTEST=1 makes a ONE-rank RCCL ("nccl") group count as data-parallel, so the single GPU of the test
     box drives every collective of the multi-GPU path for real - SwitchNorm statistic all-reduces forward and

@@ -403,3 +403,46 @@ def test_unet_snws_cpu_runnable_configuration_vs_oracle(dtype):
         assert l2(logits, logits_ref) < 1.5 * noise + 1e-2
         assert abs(float(loss) - loss_ref) < 2e-2 * abs(loss_ref)
         assert med < 1.5 * gnoise + 5e-2
+
+
+def test_predict_disk_full_fy4a_disk_matches_tile_by_tile():
+    """Full-disk inference at its real size: one 14 x 2748 x 2748 disk -> the 36 tiles of 512 x 512 the reference's
+    gen_tiles_offs gives (offsets checked against the fixture generated from utils/gen_tiles_offs.py), 12 tiles per
+    forward pass, arg-max stitched on the device - against the reference's own flow, predict.py:183-215,248-253: one
+    tile per forward, torch.max over the class axis, written into the full array in list order (a later tile
+    overwrites an earlier one where the pulled-back last row / column overlaps).  Must be equal pixel for pixel, and
+    the Evaluator's confusion matrix of the stitched map must equal the oracle's."""
+    import os
+    import numpy as np
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from oracle import snws_oracle as O
+    from snws import tiles
+    from utils.metrics import Evaluator
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g78_misc.npz"))
+    assert tuple(g["tiles0_args"]) == (2748, 2748, 512, 0)
+    offs = tiles.gen_tiles_offs(2748, 2748, 512, 0)
+    assert len(offs) == 36 and np.array_equal(np.array(offs, np.int64), g["tiles0"])
+    torch.manual_seed(3)
+    model = UNet3p_SNws(14, 16, 10, 1, 1).to(DEV)
+    model.compute_dtype = torch.bfloat16
+    img = (torch.rand(2, 14, 128, 128) * 255.0).to(DEV)
+    model.train()
+    with torch.no_grad():
+        for _ in range(3):          # give the running buffers (zero at construction) real values
+            model(img)
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    disk = (torch.rand((14, 2748, 2748), generator=gen) * 255.0).to(device=DEV, dtype=torch.bfloat16)
+    got = tiles.predict_disk(model, disk, block=512, overlap=0, tiles_per_forward=12)
+    assert got.shape == (2748, 2748) and got.dtype == torch.int64
+    ref = torch.zeros((2748, 2748), dtype=torch.int64, device=DEV)
+    model.eval()
+    with torch.no_grad():
+        for (x, y) in offs:
+            logits = model(disk[None, :, y:y + 512, x:x + 512])
+            ref[y:y + 512, x:x + 512] = torch.max(logits[0], 0)[1]
+    assert torch.equal(got, ref)
+    assert len(torch.unique(got)) > 1           # not a degenerate map
+    gt = torch.randint(0, 10, (1, 2748, 2748), generator=gen).float()
+    ev = Evaluator(10)
+    ev.add_batch(gt.to(DEV), got[None])
+    assert np.array_equal(ev._matrix(), O.confusion_matrix(gt.numpy(), got[None].cpu().numpy(), 10).astype(np.float64))
