@@ -197,6 +197,23 @@ int snws_sn_bwd_apply_res(const void* dy, int64_t lddy, const void* x, int64_t l
                           void* dx, int64_t lddx, void* dres, int64_t lddres, int dtype, const float* ctx,
                           const float* ctxb, const float* beta, int N, int64_t HW, int C, void* stream);
 
+/* SwitchNorm forward in one call that allocates nothing and takes no side buffers: snws_sn_stats -> snws_sn_finalize
+ * -> snws_sn_mix_a -> snws_sn_mix_b -> snws_sn_apply with part / shift / ctx / pack held in a static device array of
+ * the library (snws_sn_noalloc_max_floats() floats = 16 MiB, resident on every GPU the library runs on until the
+ * process ends).  No counterpart in the reference: it exists for callers that cannot allocate device memory - code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Single-GPU statistics only (there is
+ * no point at which the caller could all-reduce `pack`); the coefficients are not returned, so it serves inference and
+ * forward-only use (training = 1 still updates the running buffers exactly as snws_sn_mix_b does).
+ * Returns SNWS_ERR_INVALID when snws_sn_noalloc_floats(N, HW, C) exceeds the array.  Every call on one GPU shares
+ * that GPU's array: calls that overlap in time on one GPU (different streams or threads) race; calls on one stream
+ * are ordered and safe. */
+int64_t snws_sn_noalloc_max_floats(void);
+int64_t snws_sn_noalloc_floats(int N, int64_t HW, int C);
+int snws_sn_apply_noalloc(const void* x, int64_t ldx, void* y, int64_t ldy, const void* residual, int64_t ldr, int dtype,
+                          const float* gamma, const float* beta, const float* mean_weight, const float* var_weight,
+                          float* running_mean, float* running_var, int N, int64_t HW, int C, float eps, float momentum,
+                          int training, int using_movavg, int using_bn, int relu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batch normalisation on the same streaming kernels - replaces nn.BatchNorm2d (+ nn.ReLU) of the OCR head
  * (modeling/UNet3p_res_ocr_SNws.py:52-79,124,257,263) and _SynchronizedBatchNorm's statistics

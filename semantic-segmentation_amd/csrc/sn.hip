@@ -948,3 +948,86 @@ extern "C" int snws_sn_bwd_apply_res(const void* dy, int64_t lddy, const void* x
     return run_bwd_apply<bf16_t, 8>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
   return run_bwd_apply<bf16_t, 1>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
 }
+
+// ------------------------------------------------------------------------------------------- no-allocation forward
+// SwitchNorm forward for callers that cannot allocate device memory (HIP graph capture, tight serving loops): the
+// side buffers the stand-alone entry points take from the caller (part, shift, ctx, pack) live in one file-scope
+// device array instead.  Each GPU holds its own copy of the array at its own address; the host keeps that address
+// per device and passes it to the kernels like any other buffer.
+namespace {
+
+constexpr int64_t SN_SCRATCH_FLOATS = (int64_t)4 << 20;  // 16 MiB per GPU
+static __device__ __align__(256) float scratch[SN_SCRATCH_FLOATS];
+
+struct ScratchTable {
+  std::atomic<float*> ptr[64];
+};
+ScratchTable g_scratch;
+
+// the device address of `scratch` on the current device (looked up once per device); nullptr + error text on failure
+float* scratch_on_current_device() {
+  int d = -1;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess || d < 0 || d >= 64) {
+    snws_set_error("snws_sn_apply_noalloc: cannot determine the current device (%s)", hipGetErrorString(e));
+    return nullptr;
+  }
+  float* p = g_scratch.ptr[d].load(std::memory_order_acquire);
+  if (p) return p;
+  void* sym = nullptr;
+  e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !sym) {
+    snws_set_error("snws_sn_apply_noalloc: hipGetSymbolAddress failed on device %d: %s", d, hipGetErrorString(e));
+    return nullptr;
+  }
+  p = static_cast<float*>(sym);
+  g_scratch.ptr[d].store(p, std::memory_order_release);
+  return p;
+}
+
+inline int64_t round64(int64_t v) { return (v + 63) / 64 * 64; }
+
+}  // namespace
+
+extern "C" int64_t snws_sn_noalloc_max_floats(void) { return SN_SCRATCH_FLOATS; }
+
+extern "C" int64_t snws_sn_noalloc_floats(int N, int64_t HW, int C) {
+  if (N < 1 || HW < 1 || C < 1) return -1;
+  const int T = sn_tiles(N, HW, C);
+  return round64((int64_t)N * T * C * 2) + round64((int64_t)N * C) + round64(ctx_off(N, C).total) + round64(2 * (int64_t)C + 1);
+}
+
+extern "C" int snws_sn_apply_noalloc(const void* x, int64_t ldx, void* y, int64_t ldy, const void* residual,
+                                     int64_t ldr, int dtype, const float* gamma, const float* beta,
+                                     const float* mean_weight, const float* var_weight, float* running_mean,
+                                     float* running_var, int N, int64_t HW, int C, float eps, float momentum,
+                                     int training, int using_movavg, int using_bn, int relu, void* stream) {
+  SN_COMMON_CHECKS("snws_sn_apply_noalloc");
+  SNWS_CHECK_ARG(x && y && gamma && beta && mean_weight && var_weight, "snws_sn_apply_noalloc: NULL pointer");
+  SNWS_CHECK_ARG(HW >= 2, "snws_sn_apply_noalloc: the unbiased variance needs at least 2 positions per image");
+  SNWS_CHECK_ARG(!using_bn || (running_mean && running_var), "snws_sn_apply_noalloc: using_bn needs the running buffers");
+  const int64_t need = snws_sn_noalloc_floats(N, HW, C);
+  SNWS_CHECK_ARG(need <= SN_SCRATCH_FLOATS,
+                 "snws_sn_apply_noalloc: N=%d HW=%lld C=%d needs %lld floats of side buffers, the static scratch array "
+                 "holds %lld; use the stand-alone entry points with caller-provided buffers",
+                 N, (long long)HW, C, (long long)need, (long long)SN_SCRATCH_FLOATS);
+  float* base = scratch_on_current_device();
+  if (!base) return SNWS_ERR_HIP;
+  const int T = sn_tiles(N, HW, C);
+  float* part = base;
+  float* shift = part + round64((int64_t)N * T * C * 2);
+  float* ctx = shift + round64((int64_t)N * C);
+  float* pack = ctx + round64(ctx_off(N, C).total);
+  // every float of part / shift / ctx / pack that a later kernel reads is written by an earlier one of this call:
+  // nothing has to start at zero, whatever the previous call left behind
+  int rc = snws_sn_stats(x, dtype, N, HW, C, ldx, part, shift, stream);
+  if (rc) return rc;
+  rc = snws_sn_finalize(part, T, shift, 1, N, HW, C, ctx, stream);
+  if (rc) return rc;
+  rc = snws_sn_mix_a(ctx, pack, N, C, stream);
+  if (rc) return rc;
+  rc = snws_sn_mix_b(ctx, pack, gamma, mean_weight, var_weight, running_mean, running_var, N, C, eps, momentum,
+                     training, using_movavg, using_bn, stream);
+  if (rc) return rc;
+  return snws_sn_apply(x, ldx, y, ldy, residual, ldr, dtype, ctx, beta, N, HW, C, relu, stream);
+}

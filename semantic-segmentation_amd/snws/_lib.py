@@ -53,6 +53,10 @@ _SIGNATURES = {
     "snws_sn_mix_a": (c_int, [P, P, c_int, c_int, P]),
     "snws_sn_mix_b": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P]),
     "snws_sn_apply": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, c_int, c_int64, c_int, c_int, P]),
+    "snws_sn_noalloc_max_floats": (c_int64, []),
+    "snws_sn_noalloc_floats": (c_int64, [c_int, c_int64, c_int]),
+    "snws_sn_apply_noalloc": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, P, P, P, c_int, c_int64, c_int,
+                                      c_float, c_float, c_int, c_int, c_int, c_int, P]),
     "snws_sn_bwd_reduce": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64, c_int, c_int,
                                    P, P]),
     "snws_sn_bwd_mix_a": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P]),
