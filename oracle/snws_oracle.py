@@ -282,10 +282,12 @@ def conv_of_upsampled_commuted(x, what, b, k, rnd=None):
 
 
 def crop_concat(a, b):
-    """UNet_SNws.py:35-39: centre-crop a to b's H,W (diff//2 from top/left), cat((a,b),1)."""
+    """UNet_SNws.py:35-39: F.pad(a, (-(dX//2), -(dX-dX//2), -(dY//2), -(dY-dY//2))) then cat((a,b),1) - a negative
+    pad crops (a larger than b: centre crop, diff//2 from the top/left), a positive one zero-pads (a smaller than b,
+    which ceil-mode pooling followed by x2 up-sampling produces on odd sizes)."""
     dY = a.shape[2] - b.shape[2]
     dX = a.shape[3] - b.shape[3]
-    a = a[:, :, dY // 2: a.shape[2] - (dY - dY // 2), dX // 2: a.shape[3] - (dX - dX // 2)]
+    a = F.pad(a, (-(dX // 2), -(dX - dX // 2), -(dY // 2), -(dY - dY // 2)))
     return torch.cat((a, b), dim=1)
 
 
@@ -626,13 +628,15 @@ def is_buffer(key):
     return key.endswith('running_mean') or key.endswith('running_var') or key.endswith('num_batches_tracked')
 
 
-def model_step(arch, state, img, target, training=True, allreduce=None, loss_div=None, act_round=None):
-    """One forward (+ backward when training) of the oracle model.  Returns logits, loss, grads dict."""
+def model_step(arch, state, img, target, training=True, allreduce=None, loss_div=None, act_round=None, dlogits=None):
+    """One forward (+ backward when training) of the oracle model.  Returns logits, loss, grads dict.  With dlogits
+    the scalar that is differentiated is sum(logits * dlogits) instead of the CE loss (inputs whose output size
+    differs from the label size: the reference's CropConcat zero-pads odd sizes upwards)."""
     params = {k: (v if is_buffer(k) else v.detach().clone().requires_grad_(training)) for k, v in state.items()}
     net = OracleNet(params, allreduce=allreduce, act_round=act_round)
     net.training = training
     logits = {'unet3p': net.unet3p, 'unet': net.unet, 'unet3p_res_ocr': net.unet3p_res_ocr}[arch](img)
-    loss = ce_loss_batch_avg(logits, target)
+    loss = ce_loss_batch_avg(logits, target) if dlogits is None else (logits * dlogits).sum()
     if loss_div is not None:
         loss = loss * (logits.shape[0] / loss_div)
     grads = {}

@@ -209,17 +209,20 @@ def full_scale_decoder(m, enc, pools=None):
         ref = enc[level]
         buf = ops.new_nhwc(ref.shape[0], 5 * f, ref.shape[2], ref.shape[3], ref.dtype, ref.device)
         parts = []
-        for src in (1, 2, 3, 4):
-            out = buf[:, len(parts) * f:(len(parts) + 1) * f]
-            if src < level:         # encoder map, max-pooled down to this level
-                parts.append(enc_cat[src](pools.get(src, 2 ** (level - src)), out=out))
-            elif src == level:
-                parts.append(enc_cat[src](enc[src], out=out))
-            else:                   # decoder map of a coarser level, up-sampled
-                if src not in zdec:
-                    zdec[src] = m.convu_cat.taps(dec[src])
-                parts.append(m.convu_cat.up(zdec[src], 2 ** (src - level), out=out))
-        # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
-        parts.append(m.conv5_cat.up(z5, 2 ** (5 - level), out=buf[:, 4 * f:5 * f]))
+        # data-parallel runs: the five branch blocks are independent, so their SwitchNorm statistics travel in ONE
+        # all-reduce (their outputs are complete when the block ends; nothing reads them before the concatenation)
+        with ops.stat_batch(getattr(m.conv_fusion[1], "process_group", None)):
+            for src in (1, 2, 3, 4):
+                out = buf[:, len(parts) * f:(len(parts) + 1) * f]
+                if src < level:         # encoder map, max-pooled down to this level
+                    parts.append(enc_cat[src](pools.get(src, 2 ** (level - src)), out=out))
+                elif src == level:
+                    parts.append(enc_cat[src](enc[src], out=out))
+                else:                   # decoder map of a coarser level, up-sampled
+                    if src not in zdec:
+                        zdec[src] = m.convu_cat.taps(dec[src])
+                    parts.append(m.convu_cat.up(zdec[src], 2 ** (src - level), out=out))
+            # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
+            parts.append(m.conv5_cat.up(z5, 2 ** (5 - level), out=buf[:, 4 * f:5 * f]))
         dec[level] = m.conv_fusion(ops.assemble(buf, parts))
     return dec[1]

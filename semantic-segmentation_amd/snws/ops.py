@@ -522,6 +522,65 @@ def sync_world(group=None):
     return 1
 
 
+# Independent SwitchNorm calls whose inputs are all available before any of their outputs is needed - the five
+# branch blocks of a UNet3+ decoder scale (modeling/UNet3p_SNws.py:127-156) - share ONE statistics all-reduce per
+# direction instead of one each: inside `with stat_batch(group):` a synchronised SwitchNorm forward writes its
+# [2C+1] payload into a slot of one buffer and defers its mixing + apply passes; leaving the block all-reduces the
+# used part of the buffer once and runs the deferred passes in order.  Outputs of calls made inside the block must
+# not be read before it ends.
+STAT_BATCH = None
+
+
+class StatBatch:
+    def __init__(self, group=None, capacity=16384):
+        self.group, self.capacity = group, capacity
+        self.buf, self.used, self.pending = None, 0, []
+
+    def slot(self, n, device):
+        if self.buf is None:
+            self.buf = torch.empty(self.capacity, dtype=torch.float32, device=device)
+        if self.used + n > self.capacity:
+            raise RuntimeError("StatBatch: capacity %d exceeded" % self.capacity)
+        t = self.buf[self.used:self.used + n]
+        self.used += n
+        return t
+
+    def flush(self):
+        if self.used:
+            _allreduce_sum(self.buf[:self.used], self.group)
+        for fn in self.pending:
+            fn()
+        self.buf, self.used, self.pending = None, 0, []
+
+    def __enter__(self):
+        global STAT_BATCH
+        if STAT_BATCH is not None:
+            raise RuntimeError("stat_batch blocks do not nest")
+        STAT_BATCH = self
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global STAT_BATCH
+        STAT_BATCH = None
+        if exc_type is None:
+            self.flush()
+        return False
+
+
+class _NoBatch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def stat_batch(group=None):
+    """Context manager: a StatBatch when the data-parallel collectives are active, else a no-op (single-GPU runs keep
+    their kernel order)."""
+    return StatBatch(group) if dp_collectives(group) else _NoBatch()
+
+
 class SNParams:
     """Plain bundle of one SwitchNorm2d's tensors and flags (module attributes, modeling/snorm.py:6-25)."""
 
@@ -564,11 +623,12 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
         T = stat_part.shape[1]
         per_image = 0
     L.call("snws_sn_finalize", _ptr(stat_part), T, _ptr(stat_shift), per_image, N, HW, C, _ptr(ctx), st)
-    pack = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
-    L.call("snws_sn_mix_a", _ptr(ctx), _ptr(pack), N, C, st)
     synced = p.sync and p.training and p.using_bn and dp_collectives(p.group)
     world = sync_world(p.group) if synced else 1
-    if synced:
+    batch = STAT_BATCH if (synced and STAT_BATCH is not None and STAT_BATCH.group is p.group) else None
+    pack = batch.slot(2 * C + 1, dev) if batch is not None else torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
+    L.call("snws_sn_mix_a", _ptr(ctx), _ptr(pack), N, C, st)
+    if synced and batch is None:
         _allreduce_sum(pack, p.group)
     gamma, beta = _f32c(p.gamma).view(-1), _f32c(p.beta).view(-1)
     mw, vw = _f32c(p.mean_weight), _f32c(p.var_weight)
@@ -576,8 +636,6 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     rv = p.running_var.view(-1) if p.using_bn else None
     if p.using_bn and (rm.dtype != torch.float32 or not rm.is_contiguous() or rv.dtype != torch.float32):
         raise TypeError("SwitchNorm2d running buffers must be contiguous float32")
-    L.call("snws_sn_mix_b", _ptr(ctx), _ptr(pack), _ptr(gamma), _ptr(mw), _ptr(vw), _ptr(rm), _ptr(rv), N, C,
-           p.eps, p.momentum, int(p.training), int(p.using_movavg), int(p.using_bn), st)
     if out is None:
         y, ldy = new_nhwc(N, C, H, W, x.dtype, dev), C
     else:       # caller-provided destination, e.g. a channel slice of a concat buffer
@@ -590,8 +648,17 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     rs, ldr = (None, 0)
     if residual is not None:
         rs, ldr = as_nhwc(residual.to(x.dtype))
-    _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), ldy, _ptr(rs), ldr,
-            dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
+    momentum, eps, training, movavg, using_bn = p.momentum, p.eps, int(p.training), int(p.using_movavg), int(p.using_bn)
+
+    def finish():       # everything after the (possibly shared) statistics all-reduce
+        L.call("snws_sn_mix_b", _ptr(ctx), _ptr(pack), _ptr(gamma), _ptr(mw), _ptr(vw), _ptr(rm), _ptr(rv), N, C,
+               eps, momentum, training, movavg, using_bn, st)
+        _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), ldy, _ptr(rs),
+                ldr, dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
+    if batch is not None:
+        batch.pending.append(finish)      # y is filled when the batch is flushed
+    else:
+        finish()
     n_global = float(N * world) if world > 1 else float(N)
     saved = dict(xs=xs, ldx=ldx, ctx=ctx, gamma=gamma, beta=beta, mw=mw, vw=vw, relu=bool(relu), shape=(N, C, H, W),
                  training=p.training, using_bn=p.using_bn, world=world, synced=synced, group=p.group, n_global=n_global,
@@ -599,11 +666,12 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     return y, saved
 
 
-def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
-    """Returns (dx, dgamma (C), dbeta (C), dmean_weight, dvar_weight[, dx_sum (C)]).  dx_sum is the closed-form
-    per-channel sum of dx, i.e. the gradient of a bias added just before the normalisation.  dres_dtype (residual
-    variant only): also produce the gradient of the residual input, [y > 0] * dy, in the apply pass when it has the
-    activation dtype; it is left in s["dres"]."""
+def sn_backward_pass1(dy, s, packb=None):
+    """First half of the SwitchNorm backward, up to the payload of the backward all-reduce: the two reductions per
+    (n, c) (or the partial sums a consumer's dgrad epilogue left), d gamma / d beta, and packb = [sum_n dm, sum_n dv]
+    (written into `packb` when given - a slot of a buffer shared by several layers).  Returns the state
+    sn_backward_pass2 continues from; the all-reduce of packb happens between the two (sn_backward, or
+    AssembleFn.backward for the layers of a concatenation)."""
     N, C, H, W = s["shape"]
     HW = H * W
     lib = L.lib()
@@ -625,7 +693,8 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
                 _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, dt, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(s["beta"]), N, HW, C,
                 int(s["relu"]), _ptr(part), st)
     ctxb = torch.empty(lib.snws_sn_ctxb_floats(N, C), dtype=torch.float32, device=dev)
-    packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    if packb is None:
+        packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
     dgamma = grad_out(grad_key(s["gamma"]), (C,), dev, acc_ok=True)
     dbeta = grad_out(grad_key(s["beta"]), (C,), dev, acc_ok=True)
     acc_a = grad_accumulates(dgamma) and grad_accumulates(dbeta)
@@ -633,8 +702,19 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
         raise RuntimeError("SwitchNorm weight and bias must be used together")
     L.call("snws_sn_bwd_mix_a", _ptr(part), T, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(ctxb), _ptr(packb), _ptr(dgamma),
            _ptr(dbeta), N, C, int(acc_a), st)
-    if s["synced"]:
-        _allreduce_sum(packb, s["group"])
+    return dict(dys=dys, lddy=lddy, yms=yms, ldym=ldym, ctxb=ctxb, packb=packb, dgamma=dgamma, dbeta=dbeta,
+                key=(dy.data_ptr(), tuple(dy.shape), tuple(dy.stride()), dy._version))
+
+
+def sn_backward_pass2(s, p1, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
+    """Second half: coefficients from the (all-reduced) packb, d mean_weight / d var_weight, the apply pass."""
+    N, C, H, W = s["shape"]
+    HW = H * W
+    st = _stream()
+    dys, lddy, yms, ldym, ctxb, packb = p1["dys"], p1["lddy"], p1["yms"], p1["ldym"], p1["ctxb"], p1["packb"]
+    dgamma, dbeta = p1["dgamma"], p1["dbeta"]
+    dt = dtype_code(dys)
+    dev = dys.device
     K = s["mw"].numel()
     dmw = grad_out(grad_key(s["mw"]), (K,), dev, acc_ok=True)
     dvw = grad_out(grad_key(s["vw"]), (K,), dev, acc_ok=True)
@@ -657,6 +737,24 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
     if want_dx_sum:
         return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw), grad_fold(dxsum)
     return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw)
+
+
+def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
+    """Returns (dx, dgamma (C), dbeta (C), dmean_weight, dvar_weight[, dx_sum (C)]).  dx_sum is the closed-form
+    per-channel sum of dx, i.e. the gradient of a bias added just before the normalisation.  dres_dtype (residual
+    variant only): also produce the gradient of the residual input, [y > 0] * dy, in the apply pass when it has the
+    activation dtype; it is left in s["dres"]."""
+    p1 = s.pop("pass1", None)
+    if p1 is not None:
+        # pass 1 and the all-reduce already ran for this layer together with its siblings (AssembleFn.backward)
+        if p1["key"] != (dy.data_ptr(), tuple(dy.shape), tuple(dy.stride()), dy._version):
+            raise RuntimeError("SwitchNorm backward: the gradient that arrived is not the one the grouped statistics "
+                               "pre-pass reduced (a block output inside a concatenation has a second consumer?)")
+    else:
+        p1 = sn_backward_pass1(dy, s)
+        if s["synced"]:
+            _allreduce_sum(p1["packb"], s["group"])
+    return sn_backward_pass2(s, p1, want_dx_sum, dx_sum_key, dres_dtype)
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm
@@ -1054,6 +1152,7 @@ class AssembleFn(torch.autograd.Function):
         if off != buf.shape[1]:
             raise ValueError("AssembleFn: parts cover %d of %d channels" % (off, buf.shape[1]))
         ctx.widths = [t.shape[1] for t in parts]
+        ctx.tags = None
         return buf.view_as(buf)
 
     @staticmethod
@@ -1062,6 +1161,18 @@ class AssembleFn(torch.autograd.Function):
         for c in ctx.widths:
             outs.append(g[:, off:off + c])
             off += c
+        tags, ctx.tags = ctx.tags, None
+        if tags:
+            # data-parallel run: the parts are SwitchNorm block outputs whose ONLY consumer is this concatenation, and
+            # all their incoming gradients exist now - run the first half of each layer's backward here and carry the
+            # five [2C] payloads in ONE all-reduce; each block's own backward then continues from its "pass1" state
+            slots = torch.empty(sum(2 * s["shape"][1] for s in tags), dtype=torch.float32, device=g.device)
+            o = 0
+            for i, s in enumerate(tags):
+                C = s["shape"][1]
+                s["pass1"] = sn_backward_pass1(outs[1 + i], s, packb=slots[o:o + 2 * C])
+                o += 2 * C
+            _allreduce_sum(slots, tags[0]["group"])
         return tuple(outs)
 
 
@@ -1077,6 +1188,13 @@ def assemble(buf, parts):
         segs += [(off + c0, c, s) for c0, c, s in tag]
         off += p.shape[1]
     y._snws_seg = segs
+    # one backward statistics all-reduce for all the parts (see AssembleFn.backward) when every part is exactly one
+    # synchronised SwitchNorm layer of the same process group
+    states = [s for _, _, s in segs]
+    if y.grad_fn is not None and len(states) == len(parts) and all(s["synced"] and s["y"] is None for s in states) and \
+            all(s["group"] is states[0]["group"] for s in states) and \
+            all(c0 == sum(q.shape[1] for q in parts[:i]) and c == parts[i].shape[1] for i, (c0, c, _) in enumerate(segs)):
+        y.grad_fn.tags = states
     return y
 
 

@@ -22,6 +22,7 @@ Reference entry points exercised (file:line in /root/reference):
   utils/loss.py:146-159           SegmentationLosses.CrossEntropyLoss
   utils/lr_scheduler.py:43-61     LR_Scheduler (poly)
   utils/gen_tiles_offs.py:3-27    gen_tiles_offs
+G9 runs modeling/UNet3p_SNws.py:42-160 a second time with bf16 storage roundings applied from outside (hooks).
 """
 import io
 import os
@@ -221,6 +222,37 @@ def gen_models(only=None):
         save("g4_" + tag, **arrays)
 
 
+def gen_unet_odd():
+    """UNet_SNws on an input whose level sizes go odd (75 -> 38 -> 19 -> 10 -> 5): CropConcat (UNet_SNws.py:35-39)
+    zero-pads the skips upwards (19 vs 20, 38 vs 40, 75 vs 80), the output is 80 x 80.  No label of that size exists,
+    so the differentiated scalar is sum(logits * dy) with a pattern dy."""
+    def run(dtype):
+        model = UNet_SNws(14, 4, 10, 1, 1)
+        det_init(model)
+        model = model.to(dtype).train()
+        img, _ = synth_batch(2, 14, 75, 131)
+        out = model(img.to(dtype))
+        dy = t32(fill(tuple(out.shape), 133, 1.0, 0.1)).to(dtype)
+        (out * dy).sum().backward()
+        res = {"logits": out.detach().numpy()}
+        for name, p in model.named_parameters():
+            res["grad:" + name] = p.grad.numpy()
+        for name, b in model.named_buffers():
+            res["buf:" + name] = b.numpy().copy()
+        return res, [n for n, _ in model.named_parameters()]
+    # gradients of the first layers are sums over 80 x 80 x 2 positions of strongly cancelling terms: the reference's
+    # own float32 run is a few 1e-3 away from its float64 run there.  Expected values come from the float64 run
+    # (stored as float32); "gap:*" records the float32 run's distance per tensor (max abs / max abs).
+    exact, names = run(torch.float64)
+    single, _ = run(torch.float32)
+    arrays = {"in_size": np.array(75), "param_names": np.array(names)}
+    for k, v in exact.items():
+        arrays[k] = v.astype(np.float32)
+        arrays["gap:" + k] = np.array(np.abs(single[k].astype(np.float64) - v).max() / max(np.abs(v).max(), 1e-30))
+    print("worst float32-vs-float64 gap of the reference:", max(float(v) for k, v in arrays.items() if k.startswith("gap:")))
+    save("g4_unet_odd", **arrays)
+
+
 # --------------------------------------------------------------------------- G5
 def gen_loss_curve(n_filters=4, name="g5_loss_curve"):
     steps = 200
@@ -344,6 +376,129 @@ def gen_misc():
     save("g78_misc", **out)
 
 
+# --------------------------------------------------------------------------- G9
+def _ste_round(t, dtype=torch.bfloat16):
+    """Value rounded to `dtype`, gradient passed straight through."""
+    return t + (t.detach().to(dtype).to(t.dtype) - t.detach())
+
+
+class _Bf16Storage:
+    """Runs the REFERENCE model as if every tensor the MI355X path stores in bf16 were stored in bf16: the
+    standardized filter, every Conv2dws output, every ConvSnRelu block output, every up-sampled map, the head's
+    filter, bias and output (straight-through rounding, arithmetic stays float32).  Implemented from outside the
+    reference: forward hooks on its modules and a wrapper around torch.nn.functional.conv2d while the model runs."""
+
+    def __init__(self, model, n_class):
+        self.model, self.n_class, self.handles, self.orig = model, n_class, [], None
+
+    def __enter__(self):
+        import torch.nn as nn
+        import torch.nn.functional as F
+        for m in self.model.modules():
+            if isinstance(m, (ref_ws.Conv2dws, nn.Sequential, nn.Upsample)) or \
+                    (isinstance(m, nn.Conv2d) and m.out_channels == self.n_class):
+                self.handles.append(m.register_forward_hook(lambda mod, inp, out: _ste_round(out)))
+        self.orig = F.conv2d
+        n_class = self.n_class
+
+        def conv2d(input, weight, bias=None, *args, **kw):
+            head = weight.shape[0] == n_class and weight.shape[2] == 1
+            return self.orig(input, _ste_round(weight), _ste_round(bias) if (head and bias is not None) else bias,
+                             *args, **kw)
+        F.conv2d = conv2d
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.conv2d = self.orig
+        for h in self.handles:
+            h.remove()
+
+
+def _pack_scaled_f16(t):
+    a = t.detach().numpy().astype(np.float64)
+    scale = float(np.abs(a).max()) or 1.0
+    return (a / scale).astype(np.float16), np.array(scale, np.float64)
+
+
+def gen_bf16_storage(warm_steps=20, n_filters=16):
+    """Reference-generated fixture for the bf16 tier: UNet3p_SNws(14, 16, 10) after `warm_steps` float32 AdamW steps
+    of the reference on learnable synthetic batches (a trained, well-conditioned state instead of a pattern-filled
+    one), parameters then rounded to bf16 values; on one more batch: the plain float32 reference step, the reference
+    step with bf16 storage roundings (see _Bf16Storage), and that step once more with every parameter moved by a
+    relative 1e-6 - how far the reference's OWN bf16-storage result moves under a change far below float32
+    resolution of the weights' effect ("self noise": two correct implementations cannot agree better)."""
+    crit = SegmentationLosses(weight=None, cuda=False).build_loss(mode="ce")
+    model = UNet3p_SNws(14, n_filters, 10, 1, 1)
+    det_init(model)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=5e-4)
+    batches = [synth_batch_learnable(4, 14, 64, 200 + j) for j in range(4)]
+    for i in range(warm_steps):
+        img, lab = batches[i % 4]
+        opt.zero_grad()
+        loss = crit(model(img), lab)
+        loss.backward()
+        opt.step()
+    print("warm-up done, loss", loss.item(), flush=True)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    img, lab = synth_batch_learnable(4, 14, 64, 211)
+    img = img.to(torch.bfloat16).float()
+
+    def run(storage, perturb=0.0):
+        model.load_state_dict(state0)
+        if perturb:
+            with torch.no_grad():
+                for k, p in enumerate(model.parameters()):
+                    p.mul_(1.0 + perturb * t32(fill(tuple(p.shape), 300 + k, 1.0)))
+        model.zero_grad()
+        model.train()
+        if storage:
+            with _Bf16Storage(model, 10):
+                out = model(img)
+                loss = crit(out, lab)
+                loss.backward()
+        else:
+            out = model(img)
+            loss = crit(out, lab)
+            loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        bufs = {n: b.detach().clone() for n, b in model.named_buffers()}
+        return out.detach().clone(), float(loss.item()), grads, bufs
+
+    def l2(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+
+    def cat(g):
+        return torch.cat([v.flatten() for v in g.values()])
+
+    lo32, loss32, g32, _ = run(False)
+    lob, lossb, gb, bufb = run(True)
+    lop, lossp, gp, _ = run(True, perturb=1e-6)
+    arrays = {"warm_steps": np.array(warm_steps), "n_filters": np.array(n_filters),
+              "logits_f32": lo32.numpy(), "loss_f32": np.array(loss32), "logits_bf16": lob.numpy(),
+              "loss_bf16": np.array(lossb),
+              "noise_logits": np.array(l2(lop, lob)), "noise_grads_all": np.array(l2(cat(gp), cat(gb))),
+              "storage_logits": np.array(l2(lob, lo32)), "storage_grads_all": np.array(l2(cat(gb), cat(g32)))}
+    names = []
+    for n, p in model.named_parameters():
+        names.append(n)
+        arrays["param:" + n] = state0[n].to(torch.bfloat16).view(torch.int16).numpy()     # exact: values are bf16
+        arrays["grad16:" + n], arrays["gscale:" + n] = _pack_scaled_f16(gb[n])
+        arrays["noise:" + n] = np.array(l2(gp[n], gb[n]))
+        arrays["storage:" + n] = np.array(l2(gb[n], g32[n]))
+    for n, b in model.named_buffers():
+        arrays["buf0:" + n] = state0[n].numpy()
+        arrays["buf1:" + n] = bufb[n].numpy()
+    arrays["param_names"] = np.array(names)
+    print("self noise: logits %.4f grads(all) %.4f | storage vs f32: logits %.4f grads(all) %.4f" %
+          (arrays["noise_logits"], arrays["noise_grads_all"], arrays["storage_logits"], arrays["storage_grads_all"]))
+    save("g9_bf16_storage", **arrays)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g78"]
     if "g1" in which:
@@ -354,6 +509,8 @@ if __name__ == "__main__":
         gen_models()
     if "g4ocr" in which:    # only the res-OCR model (the other G4 fixtures stay as committed)
         gen_models(only=("unet3p_res_ocr",))
+    if "g4odd" in which:    # UNet_SNws on an odd-sized input (CropConcat's zero-padding branch)
+        gen_unet_odd()
     if "g5" in which:
         gen_loss_curve()
     if "g5b" in which:      # MFMA-aligned widths (16..256 channels) for the bf16 tier's 200-step curve
@@ -362,3 +519,5 @@ if __name__ == "__main__":
         gen_evaluator()
     if "g78" in which:
         gen_misc()
+    if "g9" in which:       # bf16-storage run of the reference (not part of the default list: takes a few minutes)
+        gen_bf16_storage()

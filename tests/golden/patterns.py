@@ -80,3 +80,18 @@ def synth_batch_learnable(B, C, S, k):
     q = np.clip(np.floor(acc / 25.0 / 25.6), 0, 9).astype(np.float32)
     q[:, ::31, ::29] = 255.0
     return img, t32(q)
+
+
+def load_bf16_storage_fixture(g):
+    """g9_bf16_storage.npz -> (state_dict of float32 tensors whose parameter values are exact bf16 numbers, image,
+    label, expected gradients as float64 tensors).  Parameters are stored as bf16 bit patterns, the expected
+    gradients as per-tensor scale x float16."""
+    state, grads = {}, {}
+    for n in [str(k) for k in g["param_names"]]:
+        state[n] = torch.from_numpy(g["param:" + n].copy()).view(torch.bfloat16).float()
+        grads[n] = torch.from_numpy(g["grad16:" + n].astype(np.float64)) * float(g["gscale:" + n])
+    for k in g.files:
+        if k.startswith("buf0:"):
+            state[k[5:]] = torch.from_numpy(g[k].copy())
+    img, lab = synth_batch_learnable(4, 14, 64, 211)
+    return state, img.to(torch.bfloat16).float(), lab, grads

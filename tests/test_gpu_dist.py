@@ -222,7 +222,9 @@ def test_two_rank_flat_trainer_step_equals_full_batch_step(tmp_path):
     assert logs[0] == logs[1] and len(logs[0]) > 10
     n_sn = sum(1 for ln in logs[0] if ln.startswith("sn "))
     print("statistic all-reduces per step:", n_sn)
-    assert n_sn <= 68
+    # 34 SwitchNorm calls: the 10 encoder blocks and the 4 fusion blocks reduce alone, the 5 branch blocks of each of
+    # the 4 decoder scales share one all-reduce -> 18 forward + 18 backward instead of 68
+    assert n_sn == 36
 
 
 def test_rccl_path_with_one_rank_group():

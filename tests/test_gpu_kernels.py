@@ -271,8 +271,43 @@ def test_conv2dws_mfma_bf16_vs_oracle(case):
 
 
 def test_conv_mfma_exact_small_integers():
-    """Integer-valued data whose products and sums are exact in bf16/f32: the MFMA path must reproduce the direct
-    kernels' result bit for bit (catches any fragment / tap / swizzle mix-up that random data could blur)."""
+    """Integer-valued inputs, filters and output gradients: every product and every partial sum is an integer below
+    2^24, exact in bf16 storage / f32 accumulation whatever the summation order, so the MFMA kernels (forward,
+    dgrad, wgrad, bias gradient) must reproduce the direct kernels fed the SAME filter - and the exact integer
+    convolution computed on the CPU in float64 - bit for bit (catches any fragment / tap / swizzle mix-up that random
+    data would blur into a tolerance)."""
+    from snws import ops
+    torch.manual_seed(5)
+    for (N, Cin, Cout, H, W, k) in ((1, 64, 64, 24, 40, 3), (2, 32, 128, 17, 23, 3), (1, 128, 64, 16, 32, 1)):
+        w = torch.randint(-2, 3, (Cout, Cin, k, k)).float()
+        b = torch.randint(-4, 5, (Cout,)).float()
+        x = torch.randint(-3, 4, (N, Cin, H, W)).float()
+        dy = torch.randint(-2, 3, (N, Cout, H, W)).float()
+        xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, wr, br, 1, (k - 1) // 2)
+        yr.backward(dy.double())
+        xg = x.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dyg = dy.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wg, bg = w.to(DEV), b.to(DEV)
+        cfg = ops.ConvCfg(w.shape, 1, (k - 1) // 2, 1, 1)
+        prep = ops.PreparedWeight(wg, cfg, True, standardize=False)
+        res = {}
+        for name, direct in (("mfma", False), ("direct", True)):
+            y, _, saved = ops.conv_forward(xg, prep, bg, force_direct=direct)
+            assert saved[3] == (not direct)          # the path that was asked for did run
+            dx, dw, db = ops.conv_backward(dyg, prep, saved, wg, True, True, True)
+            res[name] = (y, dx, dw, db)
+        for a, c, what in zip(res["mfma"], res["direct"], ("fwd", "dgrad", "wgrad", "dbias")):
+            assert torch.equal(a, c), (what, N, Cin, Cout, k)
+        y, dx, dw, db = res["mfma"]
+        assert torch.equal(y.float().cpu(), yr.detach().to(torch.bfloat16).float())
+        assert torch.equal(dx.float().cpu(), xr.grad.to(torch.bfloat16).float())
+        assert torch.equal(dw.cpu().double(), wr.grad) and torch.equal(db.cpu().double(), br.grad)
+
+
+def test_conv2dws_mfma_matches_direct_kernels():
+    """Conv2dws through the MFMA path against the same module pinned to the direct kernels: the direct path keeps
+    the standardized filter in f32, the MFMA path rounds it to bf16, so they agree at bf16 resolution of the filter."""
     import modeling.weightstd as ws
     torch.manual_seed(5)
     N, Cin, Cout, H, W = 1, 64, 64, 24, 40
@@ -284,7 +319,6 @@ def test_conv_mfma_exact_small_integers():
         conv.force_direct = True
         conv._prep = None
         y_direct = conv(xg.float()).float()
-    # same standardized weights; the direct path keeps them in f32, so compare at bf16 resolution of the weights
     assert relerr(y_fast, y_direct) < 2e-2
 
 
@@ -773,6 +807,57 @@ def test_unet3p_bf16_vs_oracle():
     print("gradient L2 rel error vs f32 oracle: median %.3g; bf16-storage oracle vs f32 oracle: median %.3g"
           % (statistics.median(e_all), statistics.median(d_all)))
     assert statistics.median(e_all) < 1.5 * statistics.median(d_all) + 5e-2
+
+
+def test_unet3p_bf16_vs_reference_run_with_bf16_storage():
+    """Whole-model bf16 bar against REFERENCE output: fixture g9 holds the reference UNet3p_SNws(14, 16, 10) in a
+    trained state (20 AdamW steps), run (a) in plain float32 and (b) with bf16 storage roundings applied to the
+    reference from outside, plus how far (b) moves when the parameters move by a relative 1e-6 (the reference's own
+    bf16 self-noise: logits 0.65 %, all gradients together 1.6 %, L2).
+    Gated here for the MFMA path: logits and loss within 2e-2 of BOTH reference runs; the whole gradient vector
+    within 2e-2 + the recorded self-noise of (b) (two exact evaluations of the same bf16-storage network differ by that
+    much), and within 1.5x the storage-vs-float32 distance of the float32 gradient; per-tensor medians likewise."""
+    import statistics
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    g = load("g9_bf16_storage")
+    state, img, lab, ref_grads = patterns.load_bf16_storage_fixture(g)
+    model = UNet3p_SNws(14, int(g["n_filters"]), 10, 1, 1)
+    sd = model.state_dict()
+    model.load_state_dict({k: state[k].reshape(sd[k].shape) for k in sd})
+    model = model.to(DEV).train()
+    model.compute_dtype = torch.bfloat16
+    logits = model(img.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, lab.to(DEV).long(), ignore_index=255) / img.shape[0]
+    loss.backward()
+
+    def l2(a, b):
+        a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+        return float((a - b).norm() / max(float(b.norm()), 1e-30))
+    noise_l, noise_g = float(g["noise_logits"]), float(g["noise_grads_all"])
+    e_b, e_f = l2(logits, g["logits_bf16"]), l2(logits, g["logits_f32"])
+    names = [str(n) for n in g["param_names"]]
+    params = dict(model.named_parameters())
+    got = torch.cat([params[n].grad.flatten().double().cpu() for n in names])
+    ref = torch.cat([ref_grads[n].flatten() for n in names])
+    e_g = l2(got, ref)
+    per = [l2(params[n].grad, ref_grads[n].reshape(params[n].shape)) for n in names if n.endswith(".0.weight")]
+    per_noise = [float(g["noise:" + n]) for n in names if n.endswith(".0.weight")]
+    print("logits: vs reference-with-bf16-storage %.4g (its self-noise %.4g), vs float32 reference %.4g (storage alone "
+          "%.4g); loss %.6f vs %.6f / %.6f; gradients (all, L2): %.4g (self-noise %.4g, storage alone %.4g); conv "
+          "filters per tensor: median %.4g, worst %.4g (self-noise median %.4g, worst %.4g)"
+          % (e_b, noise_l, e_f, float(g["storage_logits"]), float(loss), float(g["loss_bf16"]), float(g["loss_f32"]),
+             e_g, noise_g, float(g["storage_grads_all"]), statistics.median(per), max(per),
+             statistics.median(per_noise), max(per_noise)))
+    assert e_b < 2e-2 and e_f < 2e-2
+    assert abs(float(loss) - float(g["loss_bf16"])) < 2e-2 * float(g["loss_bf16"])
+    assert abs(float(loss) - float(g["loss_f32"])) < 2e-2 * float(g["loss_f32"])
+    assert e_g < 2e-2 + noise_g
+    assert statistics.median(per) < 2e-2 + statistics.median(per_noise)
+    for n in names:
+        assert torch.isfinite(params[n].grad).all(), n
+    for k, b in model.named_buffers():
+        ref_b = torch.from_numpy(g["buf1:" + k])
+        assert float((b.detach().cpu() - ref_b).abs().max()) <= 2e-2 * float(ref_b.abs().max()) + 1e-4, k
 
 
 # ================================================================== 200-step loss curve
@@ -1432,6 +1517,52 @@ def test_models_non_square_ragged_input_vs_oracle(arch):
             print("%s 48x80 bf16: GPU vs bf16-storage oracle %.3g; storage noise %.3g" % (arch, l2(logits, logits_r16), noise))
             assert l2(logits, logits_r16) < max(2e-2, 0.6 * noise)
             assert abs(float(loss.detach()) - loss_ref) < 2e-2 * abs(loss_ref)
+
+
+def test_unet_snws_odd_input_zero_padded_skips_golden():
+    """UNet_SNws on a 75 x 75 input (level sizes 75 / 38 / 19 / 10 / 5): every up-sampled decoder map is larger than
+    its skip and the reference's CropConcat (modeling/UNet_SNws.py:35-39) zero-pads the skip; output 80 x 80.
+    float32 tier against the reference's float64 run (fixture g4_unet_odd): logits 1e-3; each gradient 1e-3 + 3x the
+    distance of the reference's own float32 run recorded in the fixture.  bf16 tier (n_filters 16, MFMA kernels on
+    odd-sized maps): logits within 2e-2 (L2) of the oracle with the same storage points."""
+    from modeling.UNet_SNws import UNet_SNws
+    g = load("g4_unet_odd")
+    model = UNet_SNws(14, 4, 10, 1, 1)
+    patterns.det_init(model)
+    model = model.to(DEV).train()
+    img, _ = patterns.synth_batch(2, 14, int(g["in_size"]), 131)
+    logits = model(img.to(DEV))
+    assert tuple(logits.shape) == (2, 10, 80, 80)
+    dy = patterns.t32(patterns.fill(tuple(logits.shape), 133, 1.0, 0.1))
+    (logits * dy.to(DEV)).sum().backward()
+    assert relerr(logits, g["logits"]) < 1e-3 + 3 * float(g["gap:logits"])
+    for name, p in model.named_parameters():
+        tol = 1e-3 + 3 * float(g["gap:grad:" + name])
+        assert relerr(p.grad, g["grad:" + name]) < tol, (name, relerr(p.grad, g["grad:" + name]), tol)
+    for name, b in model.named_buffers():
+        assert relerr(b, g["buf:" + name]) < 1e-3, name
+    # bf16 / MFMA tier on the same odd sizes
+    torch.manual_seed(23)
+    model = UNet_SNws(14, 16, 10, 1, 1)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    img = bf16_round(torch.rand(2, 14, 75, 75) * 255.0)
+    dy = bf16_round(torch.randn(2, 10, 80, 80))
+    logits_ref, _, _ = O.model_step("unet", {k: v.clone() for k, v in state.items()}, img, None, dlogits=dy)
+    logits_r16, _, _ = O.model_step("unet", {k: v.clone() for k, v in state.items()}, img, None, dlogits=dy,
+                                    act_round=torch.bfloat16)
+    model = model.to(DEV).train()
+    model.compute_dtype = torch.bfloat16
+    logits = model(img.to(DEV))
+    (logits * dy.to(DEV)).sum().backward()
+
+    def l2(a, b):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return float((a - b).norm() / max(float(b.norm()), 1e-12))
+    noise = l2(logits_r16, logits_ref)
+    print("75x75 bf16: GPU vs bf16-storage oracle %.3g; storage noise %.3g" % (l2(logits, logits_r16), noise))
+    assert l2(logits, logits_r16) < max(2e-2, 0.6 * noise)
+    for name, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
 
 
 @pytest.mark.parametrize("dims,shape", [(1, (6, 10)), (1, (4, 10, 7)), (2, (3, 10, 5, 6)), (3, (2, 10, 3, 4, 5))])

@@ -315,3 +315,58 @@ def test_loss_curve_golden_prefix():
         loss.backward()
         opt.step()
         assert abs(float(loss) - float(g["losses"][i])) <= 2e-3 * float(g["losses"][i]), i
+
+
+# ---------------------------------------------------------------- bf16 storage mode
+def test_bf16_storage_mode_matches_reference_run_with_bf16_storage():
+    """The oracle's act_round=bfloat16 mode (what the bf16 GPU tier is compared with) against the REFERENCE model run
+    with the same storage roundings applied from outside (fixture g9, tests/golden/gen_golden.py::gen_bf16_storage),
+    in a trained state.  Two float32 evaluations of the same rounded network differ by summation order only, but a
+    last-bit difference flips some bf16 roundings, and the fixture records how far the reference's own result moves
+    when its parameters move by a relative 1e-6 ("noise_*"): logits 0.65 %, all gradients together 1.6 % (L2).  The
+    oracle must be within that self-noise level of the reference: 1.5x for the logits / loss, 2x for the gradients;
+    the plain float32 oracle must reproduce the fixture's float32 logits to 1e-3."""
+    g = load("g9_bf16_storage")
+    state, img, lab, ref_grads = patterns.load_bf16_storage_fixture(g)
+    st = O.make_state("unet3p", 14, int(g["n_filters"]), 10)
+    assert set(st.keys()) == set(state.keys())
+    st = {k: state[k].reshape(st[k].shape).clone() for k in st}
+
+    def l2(a, b):
+        a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+        return float((a - b).norm() / b.norm())
+
+    lo32, loss32, _ = O.model_step("unet3p", {k: v.clone() for k, v in st.items()}, img, lab)
+    assert l2(lo32, g["logits_f32"]) < 1e-3 and abs(loss32 - float(g["loss_f32"])) < 1e-3 * float(g["loss_f32"])
+    sb = {k: v.clone() for k, v in st.items()}
+    lob, lossb, gb = O.model_step("unet3p", sb, img, lab, act_round=torch.bfloat16)
+    noise_l, noise_g = float(g["noise_logits"]), float(g["noise_grads_all"])
+    assert 1e-3 < noise_l < 2e-2 and 1e-3 < noise_g < 5e-2
+    assert l2(lob, g["logits_bf16"]) < 1.5 * noise_l
+    assert abs(lossb - float(g["loss_bf16"])) < 1.5 * noise_l * float(g["loss_bf16"])
+    names = [str(n) for n in g["param_names"]]
+    got = torch.cat([gb[n].flatten().double() for n in names])
+    ref = torch.cat([ref_grads[n].flatten() for n in names])
+    assert l2(got, ref) < 2.0 * noise_g
+    for k in sb:
+        if O.is_buffer(k):
+            close(sb[k].double(), g["buf1:" + k].astype(np.float64), rtol=2e-2, atol=1e-4)
+
+
+def test_unet_odd_input_golden():
+    """UNet_SNws on a 75 x 75 input: ceil-mode pooling + x2 up-sampling leave decoder maps larger than the skips and
+    the reference's CropConcat zero-pads the skips (UNet_SNws.py:35-39); output 80 x 80."""
+    g = load("g4_unet_odd")
+    st = _state_from_pattern("unet", dtype=torch.float64)      # the fixture holds the reference's float64 run
+    img, _ = patterns.synth_batch(2, 14, int(g["in_size"]), 131)
+    dy = patterns.t32(patterns.fill(tuple(g["logits"].shape), 133, 1.0, 0.1))
+    logits, _, grads = O.model_step("unet", st, img.double(), None, training=True, dlogits=dy.double())
+    assert tuple(logits.shape) == (2, 10, 80, 80)
+    close(logits, g["logits"], rtol=1e-6, atol=1e-6)
+    for name in g["param_names"]:
+        name = str(name)
+        ref = g["grad:" + name]
+        assert np.abs(grads[name].numpy() - ref).max() <= 1e-6 * np.abs(ref).max() + 1e-9, name
+    for k in st:
+        if O.is_buffer(k):
+            close(st[k].double(), g["buf:" + k].astype(np.float64), rtol=1e-6)
