@@ -99,7 +99,8 @@ int snws_conv_direct_wgrad(const snws_conv_desc* d, int dtype, const void* x, co
  *          of the ROUNDED output for SwitchNorm: stat_part[((n*T + t)*C_out + c)*2 + {0,1}] = sum and sum of
  *          squares of (y - bias[c]) over tile t's valid pixels, T = snws_conv_mfma_tiles(H, W).
  *   dgrad: the same kernel run on dy with pack_dgrad (desc as for fwd; reads C_out channels, writes C_in).
- *   wgrad: dw_ohwi f32 (O, kh, kw, C_in) and dbias (O) are ACCUMULATED into with float atomics (zero them first). */
+ *   wgrad: dw_ohwi f32 (O, kh, kw, C_in) and dbias (O) are ACCUMULATED into with float atomics (zero them first);
+ *          the order of the adds varies from run to run - snws_conv_mfma_wgrad_det is the reproducible form. */
 int snws_conv_mfma_tiles(int H, int W);
 int snws_conv_mfma_fwd(const snws_conv_desc* d, const void* x, const void* pack_fwd, const float* bias, void* y,
                        float* stat_part, void* stream);
@@ -126,6 +127,14 @@ int snws_conv_mfma_dgrad_sn(const snws_conv_desc* d, const void* dy, const void*
                             const snws_sn_bwd_seg* segs, int n_segs, void* stream);
 int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
                          void* stream);
+/* Bit-reproducible wgrad (autograd of F.conv2d, modeling/weightstd.py:18, w.r.t. the filter and the bias): the same
+ * kernels, but every workgroup stores its partial filter tile to `workspace` with plain stores and a second kernel
+ * sums the partials in a fixed order.  dw_ohwi (O, kh, kw, C_in) is OVERWRITTEN (no zero-fill needed); dbias (O),
+ * when non-NULL, is ADDED to by one thread per channel (zero it first, or let it hold an earlier use's gradient).
+ * workspace: snws_conv_mfma_wgrad_workspace_bytes(d) bytes of device memory, 16-byte aligned, contents irrelevant. */
+int64_t snws_conv_mfma_wgrad_workspace_bytes(const snws_conv_desc* d);
+int snws_conv_mfma_wgrad_det(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SwitchNorm - replaces SwitchNorm2d.forward, modeling/snorm.py:41-81, fused with the ReLU that follows it

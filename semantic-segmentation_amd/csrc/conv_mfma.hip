@@ -534,11 +534,18 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
 }
 
 // ------------------------------------------------------------------------------------------------- wgrad
+// Flush modes of the wgrad kernels.  part == nullptr: float atomics into dw / dbias (the caller zeroed them; the
+// order of the adds, hence the last bits of the result, varies from run to run).  part != nullptr: every workgroup
+// stores its partial tile with plain coalesced stores to part[(split * npairs + pair) * E ...] (E = elements of a
+// channel tile, in the kernel's own register order) and its bias partial to pbias[(split * coTiles + cot) * TC ...];
+// wgrad_reduce_kernel then sums the splits in a fixed order - bit-reproducible, and cheaper than the atomics.
 struct WgradArgs {
   const bf16_t* x;
   const bf16_t* dy;
   float* dw;
   float* dbias;
+  float* part;
+  float* pbias;
   int N, H, W, Cin, Cout;   // Cin: channels of x that take part (multiple of 16); dw rows have Cin entries
   int64_t ldx, lddy;
   int tilesX, tilesY, coTiles, ciTiles, tilesPerSplit;
@@ -687,19 +694,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
   const int ci = cit * CIC + ci_half * 32 + (lane & 31);
   const bool ci_ok = (CIC == 64 || (lane & 31) < 16) && ci < a.Cin;
+  if (a.part) {   // partial tile [tap][r][wave][lane] (the CIC = 16 variant's two pixel-row halves are summed by the reducer)
+    float* o = a.part + ((int64_t)split * npairs + pair) * (TAPS * 16 * 256) + tid;
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) {
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cot * 64 + co_half * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (ci_ok && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * TAPS + t) * a.Cin + ci, acc[t][r]);
+      for (int r = 0; r < 16; ++r) o[(t * 16 + r) * 256] = acc[t][r];
+  } else {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * 64 + co_half * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ci_ok && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * TAPS + t) * a.Cin + ci, acc[t][r]);
+      }
     }
   }
   if (a.dbias && cit == 0) {
     b_lds[tid] = bsum;
     __syncthreads();
-    if (tid < 64 && cot * 64 + tid < a.Cout)
-      atomicAdd(a.dbias + cot * 64 + tid, b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192]);
+    if (tid < 64) {
+      const float v = b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192];
+      if (a.part) a.pbias[((int64_t)split * a.coTiles + cot) * 64 + tid] = v;
+      else if (cot * 64 + tid < a.Cout) atomicAdd(a.dbias + cot * 64 + tid, v);
+    }
   }
 }
 
@@ -835,16 +853,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1_kernel(WgradArgs a) {
     const int i = wave >> 1, h = wave & 1;
     const int ci = cit * 64 + h * 32 + (lane & 31);
     const bool ci_ok = ci < a.Cin;
+    float* po = a.part ? a.part + ((int64_t)split * npairs + pair) * 4096 + tid : nullptr;   // [r][wave = quadrant][lane]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) v += red[((w * 4 + wave) * 16 + r) * 64 + lane];
       const int co = cot * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (ci_ok && co < a.Cout) atomicAdd(a.dw + (int64_t)co * a.Cin + ci, v);
+      if (po) po[r * 256] = v;
+      else if (ci_ok && co < a.Cout) atomicAdd(a.dw + (int64_t)co * a.Cin + ci, v);
     }
   }
-  if (want_bias && tid < 64 && cot * 64 + tid < a.Cout) atomicAdd(a.dbias + cot * 64 + tid, bias_sum);
+  if (want_bias && tid < 64) {
+    if (a.part) a.pbias[((int64_t)split * a.coTiles + cot) * 64 + tid] = bias_sum;
+    else if (cot * 64 + tid < a.Cout) atomicAdd(a.dbias + cot * 64 + tid, bias_sum);
+  }
 }
 
 // 1x1 wgrad for wide layers (both channel counts above 64): a 128x128 (out, in) channel tile per workgroup, one 64x64
@@ -858,6 +881,8 @@ struct Wgrad1wArgs {
   const bf16_t* dy;
   float* dw;
   float* dbias;
+  float* part;
+  float* pbias;
   int64_t P;                 // N*H*W pixels
   int Cin, Cout;
   int64_t ldx, lddy;
@@ -974,6 +999,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1w_kernel(Wgrad1wArgs a) {
   }
 
   // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
+  float* po = a.part ? a.part + ((int64_t)split * npairs + pair) * 16384 + tid : nullptr;   // [i][h][r][wave][lane]
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -983,12 +1009,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1w_kernel(Wgrad1wArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = cot * 128 + co_q * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (ci_ok && co < a.Cout) atomicAdd(a.dw + (int64_t)co * a.Cin + ci, acc[i][h][r]);
+        if (po) po[((i * 2 + h) * 16 + r) * 256] = acc[i][h][r];
+        else if (ci_ok && co < a.Cout) atomicAdd(a.dw + (int64_t)co * a.Cin + ci, acc[i][h][r]);
       }
     }
   }
-  if (want_bias && tid < 128 && cot * 128 + tid < a.Cout)   // the loop's last barrier ordered every wave's partials
-    atomicAdd(a.dbias + cot * 128 + tid, b_lds[tid] + b_lds[tid + 128] + b_lds[tid + 256] + b_lds[tid + 384]);
+  if (want_bias && tid < 128) {   // the loop's last barrier ordered every wave's partials
+    const float v = b_lds[tid] + b_lds[tid + 128] + b_lds[tid + 256] + b_lds[tid + 384];
+    if (a.part) a.pbias[((int64_t)split * a.coTiles + cot) * 128 + tid] = v;
+    else if (cot * 128 + tid < a.Cout) atomicAdd(a.dbias + cot * 128 + tid, v);
+  }
 }
 
 // 3x3 wgrad over 64-wide in-channel tiles.  The generic kernel above reads one B fragment from LDS per MFMA, which
@@ -1180,19 +1210,32 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
   const int ci = cit * 64 + ci_half * 32 + (lane & 31);
   const bool ci_ok = ci < a.Cin;
+  if (a.part) {   // partial tile [tap][h][r][in-channel half][lane]: which wave holds a tap varies, the slot does not
+    float* o = a.part + ((int64_t)split * npairs + pair) * 36864 + ci_half * 64 + lane;
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cot * 64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (ci_ok && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + (T0 + i)) * a.Cin + ci, acc[i][h][r]);
+        for (int r = 0; r < 16; ++r) o[(((T0 + i) * 2 + h) * 16 + r) * 128] = acc[i][h][r];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cot * 64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (ci_ok && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + (T0 + i)) * a.Cin + ci, acc[i][h][r]);
+        }
       }
     }
   }
-  if (want_bias && tid < 64 && cot * 64 + tid < a.Cout)   // the loop's last barrier ordered every wave's partials
-    atomicAdd(a.dbias + cot * 64 + tid, b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192]);
+  if (want_bias && tid < 64) {   // the loop's last barrier ordered every wave's partials
+    const float v = b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192];
+    if (a.part) a.pbias[((int64_t)split * a.coTiles + cot) * 64 + tid] = v;
+    else if (cot * 64 + tid < a.Cout) atomicAdd(a.dbias + cot * 64 + tid, v);
+  }
 }
 
 template <bool BIAS>
@@ -1203,6 +1246,124 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(WgradArgs a) {
   const int tg = __builtin_amdgcn_readfirstlane(((wave >> 1) ^ (bid >> 5)) & 1);
   if (tg == 0) wgrad9_body<true, BIAS>(a, smem, bid);
   else wgrad9_body<false, BIAS>(a, smem, bid);
+}
+
+// ------------------------------------------------------------------------------------------------- wgrad reduce
+// Sums the per-workgroup partial tiles of a wgrad launch in a fixed order and writes (OVERWRITES) the f32 gradient
+// dw (O, taps, Cin); the bias partials are summed the same way and ADDED to dbias by one thread per channel (no
+// atomics: kernels on a stream run one after the other, so the result is bit-reproducible).
+// kind: 0 generic 64-wide, 1 generic C_in = 16 (its two pixel-row halves hold partial sums of the same outputs),
+//       2 wgrad1, 3 wgrad1w, 4 wgrad9 - the register orders the kernels above store their tiles in.
+struct WgradReduceArgs {
+  const float* part;
+  const float* pbias;
+  float* dw;
+  float* dbias;
+  int kind, taps, E, TC;           // E = floats per partial tile, TC = channels per out-channel tile
+  int npairs, splits, coTiles, Cin, Cout;
+  int main_blocks;                 // blocks [0, main_blocks) reduce tiles, the rest bias partials
+};
+
+__device__ __forceinline__ bool wgrad_decode(int kind, int e, int cot, int cit, int& co, int& tap, int& ci) {
+  if (kind == 4) {          // [tap][h][r][in-channel half][lane]
+    const int lane = e & 63, cih = (e >> 6) & 1, q = e >> 7;
+    const int r = q & 15, h = (q >> 4) & 1;
+    tap = q >> 5;
+    co = cot * 64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    ci = cit * 64 + cih * 32 + (lane & 31);
+    return true;
+  }
+  if (kind == 3) {          // [i][h][r][wave][lane], wave = (out quadrant, in quadrant)
+    const int lane = e & 63, wave = (e >> 6) & 3, idx = e >> 8;
+    const int r = idx & 15, h = (idx >> 4) & 1, i = idx >> 5;
+    tap = 0;
+    co = cot * 128 + (wave & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    ci = cit * 128 + (wave >> 1) * 64 + h * 32 + (lane & 31);
+    return true;
+  }
+  if (kind == 2) {          // [r][wave = quadrant (i, h)][lane]
+    const int lane = e & 63, wave = (e >> 6) & 3, r = e >> 8;
+    tap = 0;
+    co = cot * 64 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    ci = cit * 64 + (wave & 1) * 32 + (lane & 31);
+    return true;
+  }
+  // generic kernel: [tap][r][wave][lane], wave = (out half, in half | pixel-row half)
+  const int lane = e & 63, wave = (e >> 6) & 3, q = e >> 8;
+  const int r = q & 15;
+  tap = q >> 4;
+  co = cot * 64 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  if (kind == 1) {          // waves 2, 3 hold the second pixel-row half of the same outputs: summed into waves 0, 1
+    ci = lane & 31;
+    return (wave >> 1) == 0 && (lane & 31) < 16;
+  }
+  ci = cit * 64 + (wave >> 1) * 32 + (lane & 31);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
+  __shared__ float4 red[3][64];
+  __shared__ float bred[3][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if ((int)blockIdx.x < a.main_blocks) {
+    // block = 256 consecutive tile elements (float4 per lane) x 4 interleaved split classes (one per wave)
+    const int64_t g = (int64_t)blockIdx.x * 256 + lane * 4;
+    const int pair = (int)(g / a.E), e = (int)(g - (int64_t)pair * a.E);
+    const int64_t stride = (int64_t)a.npairs * a.E;
+    const float* p = a.part + (int64_t)pair * a.E + e;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto add = [](float4& acc, const float4 v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; };
+    int s = w;
+    for (; s + 12 < a.splits; s += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)s * stride);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 4) * stride);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 8) * stride);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 12) * stride);
+      add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
+    }
+    for (; s < a.splits; s += 4) add(s0, *reinterpret_cast<const float4*>(p + (int64_t)s * stride));
+    add(s0, s1); add(s2, s3); add(s0, s2);
+    if (a.kind == 1) {      // fold the second pixel-row half (tile element e + 128) in
+      float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (((e >> 6) & 3) < 2)
+        for (int s_ = w; s_ < a.splits; s_ += 4) add(t0, *reinterpret_cast<const float4*>(p + 128 + (int64_t)s_ * stride));
+      add(s0, t0);
+    }
+    if (w > 0) red[w - 1][lane] = s0;
+    __syncthreads();
+    if (w == 0) {
+      add(s0, red[0][lane]); add(s0, red[1][lane]); add(s0, red[2][lane]);
+      const int cot = pair % a.coTiles, cit = pair / a.coTiles;
+      const float v[4] = {s0.x, s0.y, s0.z, s0.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int co, tap, ci;
+        if (wgrad_decode(a.kind, e + j, cot, cit, co, tap, ci) && co < a.Cout && ci < a.Cin)
+          a.dw[((int64_t)co * a.taps + tap) * a.Cin + ci] = v[j];
+      }
+    }
+  } else {
+    // bias: block = 64 channels of one out-channel tile x 4 split classes
+    const int b = (int)blockIdx.x - a.main_blocks;          // b = cot * (TC / 64) + 64-channel group
+    const int per = a.TC / 64, cot = b / per, c = (b % per) * 64 + lane;
+    const float* p = a.pbias + (int64_t)cot * a.TC + c;
+    const int64_t stride = (int64_t)a.coTiles * a.TC;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int s = w;
+    for (; s + 12 < a.splits; s += 16) {
+      s0 += p[(int64_t)s * stride]; s1 += p[(int64_t)(s + 4) * stride];
+      s2 += p[(int64_t)(s + 8) * stride]; s3 += p[(int64_t)(s + 12) * stride];
+    }
+    for (; s < a.splits; s += 4) s0 += p[(int64_t)s * stride];
+    s0 = (s0 + s1) + (s2 + s3);
+    if (w > 0) bred[w - 1][lane] = s0;
+    __syncthreads();
+    if (w == 0) {
+      s0 = ((s0 + bred[0][lane]) + bred[1][lane]) + bred[2][lane];
+      const int co = cot * a.TC + c;
+      if (co < a.Cout) a.dbias[co] += s0;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- host
@@ -1428,66 +1589,142 @@ extern "C" int snws_conv_mfma_dgrad_sn(const snws_conv_desc* d, const void* dy, 
                       nullptr, dx, d->ldx, nullptr, (hipStream_t)stream, segs, n_segs);
 }
 
-extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
-                                    void* stream) {
-  if (int rc = check_mfma_desc(d, "snws_conv_mfma_wgrad")) return rc;
-  SNWS_CHECK_ARG(x && dy && dw_ohwi, "snws_conv_mfma_wgrad: NULL pointer");
-  SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "snws_conv_mfma_wgrad: pointers must be 16-byte aligned");
-  // C_in == 16 takes the narrow variant; any other multiple of 16 the 64-wide one (channel tails read the zero page)
+namespace {
+
+// how a wgrad launch is cut: which kernel, how many (out, in) tile pairs and pixel splits
+struct WgradPlan {
+  int kind;          // as WgradReduceArgs::kind
+  int npairs, coTiles, ciTiles, splits, tilesPerSplit, ntiles;
+  int E, TC;
+  bool wide;
+};
+
+WgradPlan wgrad_plan(const snws_conv_desc* d, bool det) {
+  WgradPlan p;
   const bool c16 = d->C_in == 16, c64 = !c16;
-  WgradArgs a;
-  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw_ohwi; a.dbias = dbias;
-  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->C_in; a.Cout = d->C_out; a.ldx = d->ldx; a.lddy = d->ldy;
-  a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
-  a.coTiles = cdiv(d->C_out, 64); a.ciTiles = c64 ? cdiv(d->C_in, 64) : 1;
-  const int ntiles = d->N * a.tilesX * a.tilesY, npairs = a.coTiles * a.ciTiles;
-  // Every workgroup ends with a 64x64x9 float-atomic flush (147 KB; the chip retires ~1.3 TB/s of atomics), so a
-  // launch of few channel-tile pairs wants few, long workgroups: one resident round (256 CUs x 2).  (Measured: 64->64
-  // @512^2 650 -> 813 TFLOP/s, 128->128 @256^2 703 -> 924 with one round instead of 2048 workgroups.)  With many pairs
-  // the workgroups of one pixel slice share its tiles through L2 only while they walk in step, and they drift apart
-  // over a long sweep: ~32 pixel tiles per workgroup is the measured optimum then (320->320: @512^2 981 TFLOP/s with
-  // 512 workgroups, 1045 with 2048, 1158 with 8192; @256^2 1077 / 1116 / 1078 with 2048 / 3072 / 8192).
-  static const int forced_blocks = getenv("SNWS_WGRAD_BLOCKS") ? atoi(getenv("SNWS_WGRAD_BLOCKS")) : 0;
-  const int64_t sweep = (int64_t)ntiles * npairs;
-  const int target_blocks = forced_blocks > 0 ? forced_blocks
-                            : sweep >= 32ll * 2048 ? (int)(sweep / 32 < 8192 ? sweep / 32 : 8192) : 512;
-  int splits = target_blocks / npairs;   // never more than target_blocks workgroups: two extra ones cost a whole extra round
-  if (splits < 1) splits = 1;
-  if (splits > ntiles) splits = ntiles;
-  a.tilesPerSplit = cdiv(ntiles, splits);
-  splits = cdiv(ntiles, a.tilesPerSplit);
-  const unsigned grid = (unsigned)(npairs * splits);
   const int taps = d->kh * d->kw;
-  hipStream_t st = (hipStream_t)stream;
-  if (c64 && taps == 9) {
-    static const bool generic = getenv("SNWS_WGRAD_GENERIC") != nullptr;
-    if (generic) return launch_wgrad<64, 9>(a, grid, st);
-    return dbias ? launch_wgrad9<true>(a, grid, st) : launch_wgrad9<false>(a, grid, st);
-  }
-  if (c64) {
-    static const bool generic1 = getenv("SNWS_WGRAD_GENERIC") != nullptr;
-    if (generic1) return launch_wgrad<64, 1>(a, grid, st);
-    static const bool narrow1 = getenv("SNWS_WGRAD1_NARROW") != nullptr;    // A/B switch: the 64-wide 1x1 kernel
+  const int tilesX = cdiv(d->W, WG_TW), tilesY = cdiv(d->H, WG_TH);
+  p.wide = false;
+  p.coTiles = cdiv(d->C_out, 64);
+  p.ciTiles = c64 ? cdiv(d->C_in, 64) : 1;
+  p.ntiles = d->N * tilesX * tilesY;
+  p.TC = 64;
+  static const bool generic = getenv("SNWS_WGRAD_GENERIC") != nullptr;
+  static const bool narrow1 = getenv("SNWS_WGRAD1_NARROW") != nullptr;    // A/B switch: the 64-wide 1x1 kernel
+  static const int forced_blocks = getenv("SNWS_WGRAD_BLOCKS") ? atoi(getenv("SNWS_WGRAD_BLOCKS")) : 0;
+  if (c64 && taps == 1 && !generic && !narrow1 && d->C_in > 64 && d->C_out > 64) {
     // the wide kernel pays when its 128-wide tiles are mostly full (measured: 512->256 @512^2 2x the narrow kernel;
     // 320->576, whose tiles are 25 % padding, 0.85x)
     const int64_t padded = (int64_t)cdiv(d->C_in, 128) * 128 * cdiv(d->C_out, 128) * 128;
-    if (!narrow1 && d->C_in > 64 && d->C_out > 64 && padded * 5 <= (int64_t)d->C_in * d->C_out * 6) {
-      Wgrad1wArgs w;
-      w.x = a.x; w.dy = a.dy; w.dw = a.dw; w.dbias = a.dbias;
-      w.P = (int64_t)d->N * d->H * d->W; w.Cin = d->C_in; w.Cout = d->C_out; w.ldx = d->ldx; w.lddy = d->ldy;
-      w.coTiles = cdiv(d->C_out, 128); w.ciTiles = cdiv(d->C_in, 128);
-      const int64_t nt = (w.P + 127) / 128;
-      SNWS_CHECK_ARG(nt < (1ll << 31), "snws_conv_mfma_wgrad: too many pixels");
-      w.ntiles = (int)nt;
-      const int np = w.coTiles * w.ciTiles;
-      int sp = 512 / np;                       // one resident round of long workgroups (64 KB atomic flush each)
-      if (sp < 1) sp = 1;
-      if (sp > w.ntiles) sp = w.ntiles;
-      w.tilesPerSplit = cdiv(w.ntiles, sp);
-      sp = cdiv(w.ntiles, w.tilesPerSplit);
-      return dbias ? launch_wgrad1w<true>(w, (unsigned)(np * sp), st) : launch_wgrad1w<false>(w, (unsigned)(np * sp), st);
-    }
-    return dbias ? launch_wgrad1<true>(a, grid, st) : launch_wgrad1<false>(a, grid, st);
+    p.wide = padded * 5 <= (int64_t)d->C_in * d->C_out * 6;
   }
-  return taps == 9 ? launch_wgrad<16, 9>(a, grid, st) : launch_wgrad<16, 1>(a, grid, st);
+  if (p.wide) {
+    p.kind = 3; p.E = 16384; p.TC = 128;
+    p.coTiles = cdiv(d->C_out, 128); p.ciTiles = cdiv(d->C_in, 128);
+    p.npairs = p.coTiles * p.ciTiles;
+    const int64_t nt = ((int64_t)d->N * d->H * d->W + 127) / 128;
+    p.ntiles = nt < (1ll << 31) ? (int)nt : -1;
+    int sp = (forced_blocks > 0 ? forced_blocks : 512) / p.npairs;   // one resident round of long workgroups
+    if (sp < 1) sp = 1;
+    if (sp > p.ntiles) sp = p.ntiles;
+    p.tilesPerSplit = cdiv(p.ntiles, sp);
+    p.splits = cdiv(p.ntiles, p.tilesPerSplit);
+    return p;
+  }
+  p.npairs = p.coTiles * p.ciTiles;
+  if (c64 && taps == 9 && !generic) { p.kind = 4; p.E = 36864; }
+  else if (c64 && taps == 1 && !generic) { p.kind = 2; p.E = 4096; }
+  else { p.kind = c64 ? 0 : 1; p.E = taps * 4096; }
+  // Atomic flush: every workgroup ends with a 64x64x9 float-atomic flush (147 KB; the chip retires ~1.3 TB/s of
+  // atomics), so a launch of few channel-tile pairs wants few, long workgroups: one resident round (256 CUs x 2).
+  // (Measured: 64->64 @512^2 650 -> 813 TFLOP/s, 128->128 @256^2 703 -> 924 with one round instead of 2048
+  // workgroups.)  With many pairs the workgroups of one pixel slice share its tiles through L2 only while they walk
+  // in step, and they drift apart over a long sweep: ~32 pixel tiles per workgroup is the measured optimum then
+  // (320->320: @512^2 981 TFLOP/s with 512 workgroups, 1045 with 2048, 1158 with 8192; @256^2 1077 / 1116 / 1078
+  // with 2048 / 3072 / 8192).  The partial-tile flush (det) keeps the same cut: its stores are ~5x cheaper than the
+  // atomics, but every split is read back once by the reducer.
+  (void)det;
+  const int64_t sweep = (int64_t)p.ntiles * p.npairs;
+  const int target_blocks = forced_blocks > 0 ? forced_blocks
+                            : sweep >= 32ll * 2048 ? (int)(sweep / 32 < 8192 ? sweep / 32 : 8192) : 512;
+  int splits = target_blocks / p.npairs;   // never more than target_blocks workgroups: two extra ones cost a whole extra round
+  if (splits < 1) splits = 1;
+  if (splits > p.ntiles) splits = p.ntiles;
+  p.tilesPerSplit = cdiv(p.ntiles, splits);
+  p.splits = cdiv(p.ntiles, p.tilesPerSplit);
+  return p;
+}
+
+int64_t wgrad_ws_floats(const WgradPlan& p) {
+  return (int64_t)p.splits * p.npairs * p.E + (int64_t)p.splits * p.coTiles * p.TC;
+}
+
+int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
+              float* ws, int64_t ws_bytes, hipStream_t st) {
+  if (int rc = check_mfma_desc(d, fn)) return rc;
+  SNWS_CHECK_ARG(x && dy && dw_ohwi, "%s: NULL pointer", fn);
+  SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "%s: pointers must be 16-byte aligned", fn);
+  const bool det = ws != nullptr;
+  const WgradPlan p = wgrad_plan(d, det);
+  SNWS_CHECK_ARG(p.ntiles > 0, "%s: too many pixels", fn);
+  float* part = nullptr;
+  float* pbias = nullptr;
+  if (det) {
+    SNWS_CHECK_ARG(((uintptr_t)ws & 15) == 0, "%s: workspace must be 16-byte aligned", fn);
+    SNWS_CHECK_ARG(ws_bytes >= wgrad_ws_floats(p) * 4, "%s: workspace of %lld bytes, %lld needed", fn,
+                   (long long)ws_bytes, (long long)wgrad_ws_floats(p) * 4);
+    part = ws;
+    pbias = ws + (int64_t)p.splits * p.npairs * p.E;
+  }
+  const int taps = d->kh * d->kw;
+  const unsigned grid = (unsigned)(p.npairs * p.splits);
+  int rc;
+  if (p.wide) {
+    Wgrad1wArgs w;
+    w.x = (const bf16_t*)x; w.dy = (const bf16_t*)dy; w.dw = dw_ohwi; w.dbias = dbias; w.part = part; w.pbias = pbias;
+    w.P = (int64_t)d->N * d->H * d->W; w.Cin = d->C_in; w.Cout = d->C_out; w.ldx = d->ldx; w.lddy = d->ldy;
+    w.coTiles = p.coTiles; w.ciTiles = p.ciTiles; w.ntiles = p.ntiles; w.tilesPerSplit = p.tilesPerSplit;
+    rc = dbias ? launch_wgrad1w<true>(w, grid, st) : launch_wgrad1w<false>(w, grid, st);
+  } else {
+    WgradArgs a;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw_ohwi; a.dbias = dbias; a.part = part; a.pbias = pbias;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->C_in; a.Cout = d->C_out; a.ldx = d->ldx; a.lddy = d->ldy;
+    a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
+    a.coTiles = p.coTiles; a.ciTiles = p.ciTiles; a.tilesPerSplit = p.tilesPerSplit;
+    if (p.kind == 4) rc = dbias ? launch_wgrad9<true>(a, grid, st) : launch_wgrad9<false>(a, grid, st);
+    else if (p.kind == 2) rc = dbias ? launch_wgrad1<true>(a, grid, st) : launch_wgrad1<false>(a, grid, st);
+    else if (p.kind == 0) rc = taps == 9 ? launch_wgrad<64, 9>(a, grid, st) : launch_wgrad<64, 1>(a, grid, st);
+    else rc = taps == 9 ? launch_wgrad<16, 9>(a, grid, st) : launch_wgrad<16, 1>(a, grid, st);
+  }
+  if (rc || !det) return rc;
+  WgradReduceArgs r;
+  r.part = part; r.pbias = pbias; r.dw = dw_ohwi; r.dbias = dbias;
+  r.kind = p.kind; r.taps = taps; r.E = p.E; r.TC = p.TC;
+  r.npairs = p.npairs; r.splits = p.splits; r.coTiles = p.coTiles; r.Cin = d->C_in; r.Cout = d->C_out;
+  r.main_blocks = (int)((int64_t)p.npairs * p.E / 256);
+  const int bias_blocks = dbias ? p.coTiles * (p.TC / 64) : 0;
+  wgrad_reduce_kernel<<<r.main_blocks + bias_blocks, 256, 0, st>>>(r);
+  SNWS_LAUNCH_CHECK(fn);
+  return SNWS_OK;
+}
+
+}  // namespace
+
+extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
+                                    void* stream) {
+  return run_wgrad("snws_conv_mfma_wgrad", d, x, dy, dw_ohwi, dbias, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int64_t snws_conv_mfma_wgrad_workspace_bytes(const snws_conv_desc* d) {
+  if (!d || check_mfma_desc(d, "snws_conv_mfma_wgrad_workspace_bytes")) return -1;
+  const WgradPlan p = wgrad_plan(d, true);
+  if (p.ntiles <= 0) return -1;
+  return wgrad_ws_floats(p) * 4;
+}
+
+extern "C" int snws_conv_mfma_wgrad_det(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi,
+                                        float* dbias, void* workspace, int64_t workspace_bytes, void* stream) {
+  SNWS_CHECK_ARG(workspace, "snws_conv_mfma_wgrad_det: NULL workspace");
+  return run_wgrad("snws_conv_mfma_wgrad_det", d, x, dy, dw_ohwi, dbias, (float*)workspace, workspace_bytes,
+                   (hipStream_t)stream);
 }

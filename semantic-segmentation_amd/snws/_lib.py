@@ -45,6 +45,8 @@ _SIGNATURES = {
     "snws_conv_mfma_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
     "snws_conv_mfma_dgrad_sn": (c_int, [POINTER(ConvDesc), P, P, P, POINTER(SnBwdSeg), c_int, P]),
     "snws_conv_mfma_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    "snws_conv_mfma_wgrad_workspace_bytes": (c_int64, [POINTER(ConvDesc)]),
+    "snws_conv_mfma_wgrad_det": (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_int64, P]),
     "snws_sn_ctx_floats": (c_int64, [c_int, c_int]),
     "snws_sn_ctxb_floats": (c_int64, [c_int, c_int]),
     "snws_sn_stats_tiles": (c_int, [c_int, c_int64, c_int]),

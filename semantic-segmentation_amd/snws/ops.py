@@ -299,6 +299,12 @@ def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
     return y, stat, saved
 
 
+# Weight gradients through per-workgroup partial tiles and a fixed-order reduction (snws_conv_mfma_wgrad_det) instead
+# of float atomics: two runs of the same step give bit-identical gradients.  SNWS_WGRAD_ATOMIC=1 selects the atomic
+# flush (A/B measurements).
+WGRAD_DETERMINISTIC = os.environ.get("SNWS_WGRAD_ATOMIC", "0") != "1"
+
+
 # SwitchNorm-backward fusion.  A fused block tags its output with the SwitchNorm state it saved for backward
 # (tag_sn_output / assemble); a convolution that consumes a tagged tensor remembers the tags, and its dgrad launch
 # then also produces pass 1 of those layers' backward (the per-tile sums of snws_sn_bwd_reduce) while it stores the
@@ -408,12 +414,20 @@ def _conv_backward_weights(dys, lddy, prep, saved, weight, need_dw, need_db, bia
     if need_db:
         db = grad_out(bias_key, (cfg.O,), dev, zero=True, acc_ok=True)    # the wgrad kernels add to it
     if used_mfma and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
-        g = torch.zeros((cfg.O, cfg.kh, cfg.kw, c_run), dtype=torch.float32, device=dev)
         d = cfg.desc(N, H, W, c_run, ldx, lddy)
+        flops = 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw
+        ws_bytes = L.lib().snws_conv_mfma_wgrad_workspace_bytes(ctypes.byref(d)) if WGRAD_DETERMINISTIC else -1
         try:
-            flops = 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw
-            _launch("conv_mfma_wgrad_k%d" % cfg.kh, flops, "snws_conv_mfma_wgrad", ctypes.byref(d), _ptr(xs),
-                    _ptr(dys), _ptr(g), _ptr(db), _stream())
+            if ws_bytes > 0:
+                # per-workgroup partial tiles + a fixed-order reduction: bit-reproducible, and g needs no zero-fill
+                g = torch.empty((cfg.O, cfg.kh, cfg.kw, c_run), dtype=torch.float32, device=dev)
+                ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+                _launch("conv_mfma_wgrad_k%d" % cfg.kh, flops, "snws_conv_mfma_wgrad_det", ctypes.byref(d), _ptr(xs),
+                        _ptr(dys), _ptr(g), _ptr(db), _ptr(ws), ws_bytes, _stream())
+            else:
+                g = torch.zeros((cfg.O, cfg.kh, cfg.kw, c_run), dtype=torch.float32, device=dev)
+                _launch("conv_mfma_wgrad_k%d" % cfg.kh, flops, "snws_conv_mfma_wgrad", ctypes.byref(d), _ptr(xs),
+                        _ptr(dys), _ptr(g), _ptr(db), _stream())
             ldg, done = c_run, True
         except L.SnwsUnsupported:
             pass

@@ -319,13 +319,7 @@ def test_training_step_full_size_loss_decreases(which):
     assert all(l == l and l < 1e3 for l in losses), losses
     # the deeper residual + OCR variant starts slower: it must fall steadily, the plain one by more than 30 %
     assert losses[-1] < (0.7 if which == "unet3p" else 0.95) * losses[0], losses
-    # the weight-gradient atomics (and the vendor GEMMs of the OCR head) make the trajectory differ in the last digits from
-    # run to run, so a single step may tick up by a hair: the second half must fall overall, never rise by more than 2 %
-    # in one step, and fall in all but at most two of its steps
-    tail = losses[5:]
-    assert tail[-1] < tail[0], losses
-    assert all(b < 1.02 * a for a, b in zip(tail, tail[1:])), losses
-    assert sum(1 for a, b in zip(tail, tail[1:]) if b < a) >= len(tail) - 3, losses
+    assert all(b < a for a, b in zip(losses[5:], losses[6:])), losses
     assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
     rm = next(b for n, b in model.named_buffers() if n.endswith("running_mean"))
     assert bool(torch.isfinite(rm).all()) and float(rm.abs().max()) > 0

@@ -322,6 +322,83 @@ def test_conv2dws_mfma_matches_direct_kernels():
     assert relerr(y_fast, y_direct) < 2e-2
 
 
+@pytest.mark.parametrize("case", [
+    (2, 64, 64, 40, 50, 3),      # 3x3, one channel-tile pair (wgrad9)
+    (1, 320, 320, 24, 40, 3),    # 3x3, 25 pairs
+    (2, 80, 144, 19, 33, 3),     # 3x3, channel tails in both tile directions
+    (2, 16, 64, 24, 40, 3),      # C_in = 16: the narrow generic kernel (two pixel-row halves per output)
+    (2, 16, 48, 20, 20, 1),      # 1x1 with C_in = 16
+    (2, 64, 576, 16, 32, 1),     # 1x1, 64-wide kernel
+    (2, 320, 16, 32, 32, 1),     # 1x1, the classification head's shape
+    (2, 256, 128, 16, 16, 1),    # 1x1, 128-wide kernel
+])
+def test_wgrad_deterministic_flush_matches_atomic_flush_and_repeats(case):
+    """snws_conv_mfma_wgrad_det (partial tiles + fixed-order reduction) against snws_conv_mfma_wgrad (float atomics)
+    through the C ABI: same filter and bias gradient to f32 summation-order accuracy, the deterministic form bit-identical
+    over repeated launches with the workspace and the output pre-filled with different garbage, and its bias gradient
+    ADDED to what the buffer held."""
+    import ctypes
+    from snws import _lib as L
+    from snws import ops
+    N, Cin, Cout, H, W, k = case
+    torch.manual_seed(11)
+    x = torch.randn(N, H, W, Cin, device=DEV).to(torch.bfloat16)
+    dy = torch.randn(N, H, W, Cout, device=DEV).to(torch.bfloat16)
+    cfg = ops.ConvCfg((Cout, Cin, k, k), 1, (k - 1) // 2, 1, 1)
+    d = cfg.desc(N, H, W, Cin, Cin, Cout)
+    g_at = torch.zeros(Cout, k, k, Cin, device=DEV)
+    b_at = torch.zeros(Cout, device=DEV)
+    L.call("snws_conv_mfma_wgrad", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g_at.data_ptr(), b_at.data_ptr(), None)
+    nbytes = L.lib().snws_conv_mfma_wgrad_workspace_bytes(ctypes.byref(d))
+    assert nbytes > 0
+    outs = []
+    for rep, fill in enumerate((0.0, 123.0, float("nan"))):
+        ws = torch.full((nbytes // 4,), fill, device=DEV)
+        g = torch.full((Cout, k, k, Cin), fill, device=DEV)
+        b = torch.full((Cout,), 0.5, device=DEV)
+        L.call("snws_conv_mfma_wgrad_det", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), b.data_ptr(),
+               ws.data_ptr(), nbytes, None)
+        outs.append((g, b))
+    for g, b in outs[1:]:
+        assert torch.equal(g, outs[0][0]) and torch.equal(b, outs[0][1])
+    g, b = outs[0]
+    assert relerr(g, g_at) < 1e-5 and relerr(b - 0.5, b_at) < 1e-5
+    # and against the definition, in float64 on the CPU
+    xr = x.float().cpu().double().permute(0, 3, 1, 2)
+    dyr = dy.float().cpu().double().permute(0, 3, 1, 2)
+    wr = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xr, wr, None, 1, (k - 1) // 2).backward(dyr)
+    assert relerr(g.permute(0, 3, 1, 2), wr.grad) < 1e-5
+    with pytest.raises(ValueError, match="workspace"):
+        L.call("snws_conv_mfma_wgrad_det", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), b.data_ptr(),
+               ws.data_ptr(), nbytes - 16, None)
+
+
+def test_training_step_is_bit_reproducible():
+    """Two runs of three Trainer steps (flat optimizer, fused loss, bf16 MFMA path) from the same state on the same
+    batches: every loss, every parameter and every running buffer must be bit-identical - no float atomics are left
+    on the training path (weight gradients go through partial tiles and a fixed-order reduction)."""
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from snws import harness
+    batches = [patterns.synth_batch_learnable(4, 14, 64, 200 + j) for j in range(3)]
+
+    def run():
+        model = UNet3p_SNws(14, 16, 10, 1, 1)
+        patterns.det_init(model)
+        model = model.to(DEV)
+        model.compute_dtype = torch.bfloat16
+        tr = harness.Trainer(model, total_iters=100)
+        losses = [tr.step(i.to(DEV), l.to(DEV)).clone() for i, l in batches]
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        tr.close()
+        return torch.stack(losses), state
+    l0, s0 = run()
+    l1, s1 = run()
+    assert torch.equal(l0, l1), (l0, l1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 # ================================================================== SwitchNorm
 def _sn_module(g, pre):
     import modeling.snorm as sn

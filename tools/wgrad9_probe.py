@@ -24,18 +24,29 @@ for cin, cout, S in ((320, 320, 512), (320, 64, 512), (64, 64, 512), (320, 320, 
     d = cfg.desc(N, S, S, cin, cin, cout)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def run():
+    nbytes = L.lib().snws_conv_mfma_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(nbytes // 4, device="cuda:0")
+
+    def run_atomic():
         L.call("snws_conv_mfma_wgrad", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), db.data_ptr(), st)
-    for _ in range(2):
-        run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / 5
+
+    def run_det():      # partial tiles + fixed-order reduction (both kernels are inside the timed region)
+        L.call("snws_conv_mfma_wgrad_det", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), db.data_ptr(),
+               ws.data_ptr(), nbytes, st)
+    res = []
+    for run in (run_atomic, run_det):
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 5)
     fl = 2.0 * 9 * N * S * S * cin * cout
-    print("blocks %5s  wgrad 3x3 %4d->%4d @%3d^2: %.3f ms  %6.0f TFLOP/s" % (forced, cin, cout, S, t, fl / t / 1e9), flush=True)
-    del x, dy, g
+    print("blocks %5s  wgrad 3x3 %4d->%4d @%3d^2: atomic %.3f ms %6.0f TFLOP/s | partial tiles + reduce %.3f ms %6.0f TFLOP/s "
+          "(workspace %.0f MB)" % (forced, cin, cout, S, res[0], fl / res[0] / 1e9, res[1], fl / res[1] / 1e9, nbytes / 1e6),
+          flush=True)
+    del x, dy, g, ws
