@@ -306,6 +306,23 @@ int snws_argmax_stitch(const void* logits, int dtype, int64_t ld, int h, int w, 
                        int y0, int x0, int remap_background, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input-side tile preparation - replaces the numpy lines of CLOUDdataset.__getitem__,
+ * dataloaders/datasets/cloud_dataset.py:127-134.
+ *
+ * snws_tile_minmax_scale: n_tiles tiles of elems_per_tile consecutive float32 values each (a (C, H, W) tile as
+ *   gdal's ReadAsArray returns it, or a stack of them): NaN -> 0, then ((x - min) / (max - min)) * 255 with the
+ *   tile's own minimum and maximum over ALL its channels, every operation rounded to float32 like numpy's
+ *   (a constant tile gives NaN / inf exactly as numpy's 0/0 does).  y has x's layout, out_dtype SNWS_F32 or SNWS_BF16.
+ *   part: 2 * n_tiles * snws_tile_minmax_blocks(elems_per_tile) floats of scratch; minmax_out (nullable): 2 * n_tiles
+ *   floats [min, max] per tile.
+ * snws_label_remap: dst[i] = float(src[i]) with NaN -> 255, then 10 -> 0, then 255 -> 0 (cloud_dataset.py:132-134).
+ *   src_dtype: SNWS_F32 | SNWS_F64 | SNWS_I64 | SNWS_I32 | SNWS_U8. */
+int snws_tile_minmax_blocks(int64_t elems_per_tile);
+int snws_tile_minmax_scale(const float* x, void* y, int out_dtype, int n_tiles, int64_t elems_per_tile, float* part,
+                           float* minmax_out, void* stream);
+int snws_label_remap(const void* src, int src_dtype, float* dst, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused AdamW over a flat float32 buffer - replaces torch.optim.AdamW(model.parameters(), lr, weight_decay)
  * (train.py:81) stepped once per iteration (train.py:254); `lr` is the poly-schedule value of that iteration
  * (utils/lr_scheduler.py:43-70).  param/grad/exp_avg/exp_avg_sq: n floats each, 16-byte aligned; step >= 1 is the

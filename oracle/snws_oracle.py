@@ -359,6 +359,31 @@ def evaluator_metrics(cm):
 
 
 # ----------------------------------------------------------------------------
+# Input-side tile preparation (dataloaders/datasets/cloud_dataset.py:127-134)
+# ----------------------------------------------------------------------------
+def normalize_tile(img_tif):
+    """cloud_dataset.py:127-131 on one (C, H, W) float32 numpy tile: NaN -> 0, min-max over the whole tile, x 255."""
+    img_tif = np.array(img_tif, dtype=np.float32, copy=True)
+    img_tif[np.isnan(img_tif)] = 0
+    imax = img_tif.max()
+    imin = img_tif.min()
+    with np.errstate(all="ignore"):
+        img_tif = (img_tif - imin) / (imax - imin)
+        img_tif *= 255
+    return img_tif
+
+
+def remap_label(mask):
+    """cloud_dataset.py:132-137: NaN -> 255, 10 -> 0, 255 -> 0, as float32."""
+    mask = np.array(mask, copy=True)
+    if mask.dtype.kind == "f":
+        mask[np.isnan(mask)] = 255
+    mask[mask == 10] = 0
+    mask[mask == 255] = 0
+    return torch.from_numpy(mask).float().numpy()
+
+
+# ----------------------------------------------------------------------------
 # Whole models as functions of a reference-compatible state_dict
 # ----------------------------------------------------------------------------
 class OracleNet:

@@ -1,0 +1,142 @@
+// Input-side tile preparation on the device (replaces the numpy lines of CLOUDdataset.__getitem__,
+// dataloaders/datasets/cloud_dataset.py:127-134 of the reference): per-tile min-max scaling to [0, 255] with NaN -> 0,
+// and the label remap NaN -> 255, 10 -> 0, 255 -> 0.  HBM-bound streaming kernels: 2 reads + 1 write of the tile.
+// The arithmetic is the reference's, operation by operation in float32 ((x - min) / (max - min), then * 255), so the
+// result is bit-identical to numpy's; min and max do not depend on the reduction order.
+#include "common.h"
+
+namespace {
+
+constexpr int DT_THREADS = 256;
+
+__device__ __forceinline__ float nan_to_zero(float v) { return v != v ? 0.f : v; }
+
+// partial min / max of one tile: grid (blocks_per_tile, n_tiles); part[(tile * B + b) * 2 + {0, 1}]
+__global__ __launch_bounds__(DT_THREADS) void tile_minmax_kernel(const float* __restrict__ x, int64_t elems, int B,
+                                                                 float* __restrict__ part) {
+  __shared__ float smin[DT_THREADS / 64], smax[DT_THREADS / 64];
+  const int tile = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+  const float* xt = x + (int64_t)tile * elems;
+  float mn = INFINITY, mx = -INFINITY;
+  const int64_t nvec = ((reinterpret_cast<uintptr_t>(xt) & 15) == 0) ? elems / 4 : 0;
+  for (int64_t i = (int64_t)b * DT_THREADS + tid; i < nvec; i += (int64_t)B * DT_THREADS) {
+    const float4 v = *reinterpret_cast<const float4*>(xt + 4 * i);
+    const float a0 = nan_to_zero(v.x), a1 = nan_to_zero(v.y), a2 = nan_to_zero(v.z), a3 = nan_to_zero(v.w);
+    mn = fminf(fminf(mn, a0), fminf(a1, fminf(a2, a3)));
+    mx = fmaxf(fmaxf(mx, a0), fmaxf(a1, fmaxf(a2, a3)));
+  }
+  for (int64_t i = nvec * 4 + (int64_t)b * DT_THREADS + tid; i < elems; i += (int64_t)B * DT_THREADS) {
+    const float a = nan_to_zero(xt[i]);
+    mn = fminf(mn, a);
+    mx = fmaxf(mx, a);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if ((tid & 63) == 0) { smin[tid >> 6] = mn; smax[tid >> 6] = mx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < DT_THREADS / 64; ++w) { mn = fminf(mn, smin[w]); mx = fmaxf(mx, smax[w]); }
+    part[((int64_t)tile * B + b) * 2] = mn;
+    part[((int64_t)tile * B + b) * 2 + 1] = mx;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_out(T* p, float v);
+template <>
+__device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+template <typename T>
+__global__ __launch_bounds__(DT_THREADS) void tile_scale_kernel(const float* __restrict__ x, T* __restrict__ y,
+                                                                int64_t elems, int B, const float* __restrict__ part,
+                                                                float* __restrict__ minmax_out) {
+  __shared__ float s_mn, s_mx;
+  const int tile = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {   // every block folds the tile's B partials itself (B <= 64; cheaper than a third launch)
+    float mn = tid < B ? part[((int64_t)tile * B + tid) * 2] : INFINITY;
+    float mx = tid < B ? part[((int64_t)tile * B + tid) * 2 + 1] : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, o, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
+    if (tid == 0) {
+      s_mn = mn;
+      s_mx = mx;
+      if (b == 0 && minmax_out) { minmax_out[2 * tile] = mn; minmax_out[2 * tile + 1] = mx; }
+    }
+  }
+  __syncthreads();
+  const float mn = s_mn, range = s_mx - s_mn;
+  const float* xt = x + (int64_t)tile * elems;
+  T* yt = y + (int64_t)tile * elems;
+  for (int64_t i = (int64_t)b * DT_THREADS + tid; i < elems; i += (int64_t)B * DT_THREADS) {
+    // cloud_dataset.py:130-131, one rounding per operation as numpy does: subtract, divide, multiply
+    const float d = __fsub_rn(nan_to_zero(xt[i]), mn);
+    const float q = __fdiv_rn(d, range);
+    store_out<T>(yt + i, __fmul_rn(q, 255.0f));
+  }
+}
+
+template <typename S>
+__global__ __launch_bounds__(DT_THREADS) void label_remap_kernel(const S* __restrict__ src, float* __restrict__ dst,
+                                                                 int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * DT_THREADS + threadIdx.x;
+  if (i >= n) return;
+  float v = (float)src[i];
+  if (v != v) v = 255.f;                  // mask[np.isnan(mask)] = 255
+  if (v == 10.f) v = 0.f;                 // mask[mask == 10] = 0
+  if (v == 255.f) v = 0.f;                // mask[mask == 255] = 0
+  dst[i] = v;
+}
+
+}  // namespace
+
+extern "C" int snws_tile_minmax_blocks(int64_t elems_per_tile) {
+  int64_t b = (elems_per_tile + 65535) / 65536;
+  if (b < 1) b = 1;
+  if (b > 64) b = 64;
+  return (int)b;
+}
+
+extern "C" int snws_tile_minmax_scale(const float* x, void* y, int out_dtype, int n_tiles, int64_t elems_per_tile,
+                                      float* part, float* minmax_out, void* stream) {
+  SNWS_CHECK_ARG(x && y && part, "snws_tile_minmax_scale: NULL pointer");
+  SNWS_CHECK_ARG(n_tiles >= 1 && n_tiles <= 65535 && elems_per_tile >= 1,
+                 "snws_tile_minmax_scale: n_tiles %d (1..65535), elems_per_tile %lld", n_tiles, (long long)elems_per_tile);
+  SNWS_CHECK_ARG(out_dtype == SNWS_F32 || out_dtype == SNWS_BF16, "snws_tile_minmax_scale: out_dtype %d is not F32/BF16",
+                 out_dtype);
+  const int B = snws_tile_minmax_blocks(elems_per_tile);
+  hipStream_t st = (hipStream_t)stream;
+  tile_minmax_kernel<<<dim3(B, n_tiles), DT_THREADS, 0, st>>>(x, elems_per_tile, B, part);
+  SNWS_LAUNCH_CHECK("snws_tile_minmax_scale(1)");
+  if (out_dtype == SNWS_F32)
+    tile_scale_kernel<float><<<dim3(B, n_tiles), DT_THREADS, 0, st>>>(x, (float*)y, elems_per_tile, B, part, minmax_out);
+  else
+    tile_scale_kernel<bf16_t><<<dim3(B, n_tiles), DT_THREADS, 0, st>>>(x, (bf16_t*)y, elems_per_tile, B, part, minmax_out);
+  SNWS_LAUNCH_CHECK("snws_tile_minmax_scale(2)");
+  return SNWS_OK;
+}
+
+extern "C" int snws_label_remap(const void* src, int src_dtype, float* dst, int64_t n, void* stream) {
+  SNWS_CHECK_ARG(src && dst, "snws_label_remap: NULL pointer");
+  SNWS_CHECK_ARG(n >= 0, "snws_label_remap: negative size");
+  if (n == 0) return SNWS_OK;
+  const unsigned grid = (unsigned)cdiv64(n, DT_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  switch (src_dtype) {
+    case SNWS_F32: label_remap_kernel<float><<<grid, DT_THREADS, 0, st>>>((const float*)src, dst, n); break;
+    case SNWS_F64: label_remap_kernel<double><<<grid, DT_THREADS, 0, st>>>((const double*)src, dst, n); break;
+    case SNWS_I64: label_remap_kernel<int64_t><<<grid, DT_THREADS, 0, st>>>((const int64_t*)src, dst, n); break;
+    case SNWS_I32: label_remap_kernel<int><<<grid, DT_THREADS, 0, st>>>((const int*)src, dst, n); break;
+    case SNWS_U8: label_remap_kernel<unsigned char><<<grid, DT_THREADS, 0, st>>>((const unsigned char*)src, dst, n); break;
+    default: SNWS_CHECK_ARG(false, "snws_label_remap: unsupported src_dtype %d", src_dtype);
+  }
+  SNWS_LAUNCH_CHECK("snws_label_remap");
+  return SNWS_OK;
+}

@@ -78,6 +78,9 @@ _SIGNATURES = {
     "snws_bn_coeff": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, c_float, c_float, c_int, c_int, P]),
     "snws_bn_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
     "snws_bn_bwd_coeff": (c_int, [P, P, P, c_int, c_int, c_float, c_int, P]),
+    "snws_tile_minmax_blocks": (c_int, [c_int64]),
+    "snws_tile_minmax_scale": (c_int, [P, P, c_int, c_int, c_int64, P, P, P]),
+    "snws_label_remap": (c_int, [P, c_int, P, c_int64, P]),
     "snws_adamw_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
     "snws_comm_unique_id": (c_int, [P]),
     "snws_comm_init": (c_int, [P, c_int, c_int, P]),
@@ -92,7 +95,7 @@ _SIGNATURES = {
 # entry points that return a status code (the others return a value)
 _STATUS = {k for k, (res, _) in _SIGNATURES.items() if res is c_int} - {
     "snws_version", "snws_conv_out_size", "snws_conv_mfma_tiles", "snws_sn_stats_tiles", "snws_ce_blocks",
-    "snws_upconv_stat_tiles"}
+    "snws_upconv_stat_tiles", "snws_tile_minmax_blocks"}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -33,12 +33,13 @@ def gen_tiles_offs(xsize, ysize, block, overlap):
 
 @torch.no_grad()
 def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forward=12, remap_background=False,
-                 group=None, normalize=None):
+                 group=None, normalize="minmax"):
     """Class map (H, W) int64 of one (C, H, W) disk that already lives on the device.
 
     model: a network of this package in eval mode semantics (model.eval() is called); disk: float tensor (C, H, W),
-    H = ysize, W = xsize.  normalize: optional callable applied to each (n, C, block, block) tile batch before the
-    network (e.g. the per-tile min-max x255 of dataloaders/datasets/cloud_dataset.py:127-131).
+    H = ysize, W = xsize.  normalize: what is applied to each (n, C, block, block) tile batch before the network -
+    "minmax" (default): the per-tile min-max x 255 the training tiles went through
+    (dataloaders/datasets/cloud_dataset.py:127-131) on the HIP kernel of snws.data; a callable; or None.
     Under torch.distributed the tile list is dealt round-robin to the ranks; every rank returns the full map: the
     ranks' partial maps are merged with one all-reduce(max) of (tile index, class) keys, which reproduces "later
     tile wins".  No halo exchange is needed: every tile is a self-contained forward."""
@@ -68,7 +69,11 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
         for b0 in range(0, len(mine), tiles_per_forward):
             chunk = mine[b0:b0 + tiles_per_forward]
             batch = torch.stack([disk[:, y:y + block, x:x + block] for _, (x, y) in chunk])
-            if normalize is not None:
+            if normalize == "minmax":
+                from . import data
+                cd = getattr(model, "compute_dtype", None)
+                batch = data.normalize_tiles(batch, torch.bfloat16 if cd == torch.bfloat16 else torch.float32)
+            elif normalize is not None:
                 batch = normalize(batch)
             logits = model(batch)
             for j, (i, (x, y)) in enumerate(chunk):

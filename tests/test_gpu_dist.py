@@ -106,9 +106,10 @@ def _worker(rank, world, port, q):
     offs = tiles.gen_tiles_offs(160, 150, 64, 24)
     ref = torch.zeros((150, 160), dtype=torch.int64, device=dev)
     model.eval()
+    from snws import data
     with torch.no_grad():
         for (x, y) in offs:
-            ref[y:y + 64, x:x + 64] = torch.argmax(model(disk[None, :, y:y + 64, x:x + 64])[0], dim=0)
+            ref[y:y + 64, x:x + 64] = torch.argmax(model(data.normalize_tiles(disk[None, :, y:y + 64, x:x + 64]))[0], dim=0)
     errs["disk_equal"] = bool(torch.equal(got, ref))
     q.put((rank, errs, len(buckets.buckets)))
     dist.destroy_process_group()

@@ -410,7 +410,7 @@ def test_predict_disk_full_fy4a_disk_matches_tile_by_tile():
     import numpy as np
     from modeling.UNet3p_SNws import UNet3p_SNws
     from oracle import snws_oracle as O
-    from snws import tiles
+    from snws import data, tiles
     from utils.metrics import Evaluator
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g78_misc.npz"))
     assert tuple(g["tiles0_args"]) == (2748, 2748, 512, 0)
@@ -431,8 +431,8 @@ def test_predict_disk_full_fy4a_disk_matches_tile_by_tile():
     ref = torch.zeros((2748, 2748), dtype=torch.int64, device=DEV)
     model.eval()
     with torch.no_grad():
-        for (x, y) in offs:
-            logits = model(disk[None, :, y:y + 512, x:x + 512])
+        for (x, y) in offs:     # every tile scaled by its own min / max, as the training tiles were (cloud_dataset.py:127-131)
+            logits = model(data.normalize_tiles(disk[None, :, y:y + 512, x:x + 512], torch.bfloat16))
             ref[y:y + 512, x:x + 512] = torch.max(logits[0], 0)[1]
     assert torch.equal(got, ref)
     assert len(torch.unique(got)) > 1           # not a degenerate map

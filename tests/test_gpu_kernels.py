@@ -1084,13 +1084,56 @@ def test_predict_disk_matches_tile_by_tile():
         ref = torch.zeros((150, 160), dtype=torch.int64, device=DEV)
         model.eval()
         with torch.no_grad():
-            for (x, y) in offs:
-                lg = model(disk[None, :, y:y + block, x:x + block])
+            for (x, y) in offs:     # each tile scaled by its own min / max first (cloud_dataset.py:127-131), on the CPU oracle
+                tile = torch.from_numpy(O.normalize_tile(disk[:, y:y + block, x:x + block].cpu().numpy())).to(DEV)
+                lg = model(tile[None])
                 ref[y:y + block, x:x + block] = torch.argmax(lg[0], dim=0)
         got = tiles.predict_disk(model, disk, block=block, overlap=overlap, tiles_per_forward=3)
         assert got.shape == ref.shape
         # eval-mode SwitchNorm has no batch coupling, so batching tiles changes nothing: exact equality
         assert torch.equal(got, ref)
+        # without the per-tile scaling the raw values go in
+        raw = tiles.predict_disk(model, disk, block=block, overlap=overlap, tiles_per_forward=3, normalize=None)
+        ref2 = torch.zeros((150, 160), dtype=torch.int64, device=DEV)
+        with torch.no_grad():
+            for (x, y) in offs:
+                ref2[y:y + block, x:x + block] = torch.argmax(model(disk[None, :, y:y + block, x:x + block])[0], dim=0)
+        assert torch.equal(raw, ref2)
+
+
+def test_tile_minmax_scale_and_label_remap_bit_exact():
+    """The HIP tile preparation against the numpy lines of the reference's dataset (cloud_dataset.py:127-134, restated in
+    the oracle): per-tile min-max x 255 with NaN -> 0 and the label remap, bit for bit - batches of tiles, a tile whose
+    size is not a multiple of the vector width, an unaligned view, NaNs, a constant tile (0/0 -> NaN like numpy), the
+    bf16 output rounded from the float32 result, every label dtype."""
+    from snws import data
+    rng = np.random.default_rng(17)
+    for shape in ((3, 14, 64, 64), (1, 14, 37, 41), (2, 3, 5, 7), (14, 128, 128)):
+        a = (rng.standard_normal(shape) * 40.0 + 300.0).astype(np.float32)
+        a.reshape(-1)[::97] = np.nan
+        if len(shape) == 4 and shape[0] > 1:
+            a[1] = 7.5                                      # a constant tile
+        got = data.normalize_tiles(torch.from_numpy(a).to(DEV))
+        tiles_np = a if a.ndim == 4 else a[None]
+        want = np.stack([O.normalize_tile(t) for t in tiles_np]).reshape(shape)
+        # (value equality with NaN == NaN: the constant tile's 0/0 carries the host's / the device's NaN sign bit)
+        assert np.array_equal(got.cpu().numpy(), want, equal_nan=True), shape
+        got16, mm = data.normalize_tiles(torch.from_numpy(a).to(DEV), torch.bfloat16, return_minmax=True)
+        assert np.array_equal(got16.float().cpu().numpy(), torch.from_numpy(want).to(torch.bfloat16).float().numpy(),
+                              equal_nan=True), shape
+        clean = np.where(np.isnan(tiles_np), 0, tiles_np).reshape(tiles_np.shape[0], -1)
+        assert np.array_equal(mm.cpu().numpy(), np.stack([clean.min(1), clean.max(1)], 1))
+    odd = torch.from_numpy((rng.standard_normal(14 * 33 * 35 + 1) * 3).astype(np.float32)).to(DEV)[1:].view(14, 33, 35)
+    assert np.array_equal(data.normalize_tiles(odd).cpu().numpy(), O.normalize_tile(odd.cpu().numpy()))
+    lab = rng.integers(0, 12, size=(2, 33, 47)).astype(np.float32)
+    lab[0, ::5, ::3] = 255.0
+    lab[1, 1::7, ::2] = np.nan
+    for dt in (np.float32, np.float64, np.int64, np.int32, np.uint8):
+        src = np.nan_to_num(lab, nan=255.0).astype(dt) if np.dtype(dt).kind != "f" else lab.astype(dt)
+        got = data.remap_labels(torch.from_numpy(src).to(DEV))
+        assert got.dtype == torch.float32 and np.array_equal(got.cpu().numpy(), O.remap_label(src)), dt
+    with pytest.raises(RuntimeError):
+        data.normalize_tiles(torch.zeros(3, 4, 4))           # CPU tensor: no fallback
 
 
 def test_comm_single_rank_roundtrip():

@@ -370,3 +370,15 @@ def test_unet_odd_input_golden():
     for k in st:
         if O.is_buffer(k):
             close(st[k].double(), g["buf:" + k].astype(np.float64), rtol=1e-6)
+
+
+def test_tile_normalisation_and_label_remap_known_answers():
+    """cloud_dataset.py:127-137 restated (the dataset module itself needs gdal and cannot be imported): hand-checked
+    values - NaN counts as 0 in the minimum / maximum and in the result, the extremes land on 0 and 255."""
+    t = np.array([[[0.5, 1.0], [np.nan, 3.0]], [[-1.0, 2.0], [0.0, 1.0]]], np.float32)       # min -1, max 3
+    want = (np.array([[[1.5, 2.0], [1.0, 4.0]], [[0.0, 3.0], [1.0, 2.0]]], np.float32) / np.float32(4.0)) * np.float32(255)
+    assert np.array_equal(O.normalize_tile(t), want)
+    assert O.normalize_tile(t).dtype == np.float32 and np.isnan(O.normalize_tile(np.full((1, 2, 2), 3.0, np.float32))).all()
+    m = np.array([[0.0, 10.0, 255.0], [np.nan, 9.0, 3.0]], np.float32)
+    assert np.array_equal(O.remap_label(m), np.array([[0, 0, 0], [0, 9, 3]], np.float32))
+    assert np.array_equal(O.remap_label(np.array([10, 255, 4], np.uint8)), np.array([0, 0, 4], np.float32))
