@@ -136,6 +136,24 @@ int64_t snws_conv_mfma_wgrad_workspace_bytes(const snws_conv_desc* d);
 int snws_conv_mfma_wgrad_det(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
                              void* workspace, int64_t workspace_bytes, void* stream);
 
+/* float32 MFMA kernels (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulation - exactly an fmaf chain): the float32
+ * tier of the same convolution (F.conv2d at modeling/weightstd.py:18 and its autograd) for 3x3 (pad 1) / 1x1 (pad 0),
+ * stride 1, dilation 1, groups 1 and ANY channel counts; SNWS_ERR_UNSUPPORTED otherwise (use the direct kernels).
+ *   fwd:   y = conv(x, w_ohwi) + bias with w_ohwi f32 (O, kh, kw, I) as snws_ws_fwd / snws_conv_pack write it; stat_part
+ *          (nullable) [N][T][C_out][2], T = snws_conv_f32_tiles(H, W): per 8x32-pixel tile the sum and the sum of
+ *          squares of (y - bias[c]) over the tile's valid pixels - the layout snws_sn_finalize takes with shift = bias.
+ *   dgrad: dx = the same kernel run on dy with w_ihwo_flipped f32 (I, kh, kw, O) from snws_conv_f32_flip.
+ *   wgrad: dw_ohwi f32 (O, kh, kw, I) OVERWRITTEN, dbias (O, nullable) ADDED to; per-workgroup partial tiles in
+ *          `workspace` (snws_conv_f32_wgrad_workspace_bytes(d) bytes, 16-byte aligned) summed in a fixed order. */
+int snws_conv_f32_tiles(int H, int W);
+int snws_conv_f32_fwd(const snws_conv_desc* d, const float* x, const float* w_ohwi, const float* bias, float* y,
+                      float* stat_part, void* stream);
+int snws_conv_f32_flip(const float* w_ohwi, float* w_ihwo_flipped, int O, int I, int kh, int kw, void* stream);
+int snws_conv_f32_dgrad(const snws_conv_desc* d, const float* dy, const float* w_ihwo_flipped, float* dx, void* stream);
+int64_t snws_conv_f32_wgrad_workspace_bytes(const snws_conv_desc* d);
+int snws_conv_f32_wgrad(const snws_conv_desc* d, const float* x, const float* dy, float* dw_ohwi, float* dbias,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * SwitchNorm - replaces SwitchNorm2d.forward, modeling/snorm.py:41-81, fused with the ReLU that follows it
  * in ConvSnRelu (modeling/UNet3p_SNws.py:29-33), and its autograd.

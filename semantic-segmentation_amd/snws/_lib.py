@@ -47,6 +47,12 @@ _SIGNATURES = {
     "snws_conv_mfma_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "snws_conv_mfma_wgrad_workspace_bytes": (c_int64, [POINTER(ConvDesc)]),
     "snws_conv_mfma_wgrad_det": (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_int64, P]),
+    "snws_conv_f32_tiles": (c_int, [c_int, c_int]),
+    "snws_conv_f32_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
+    "snws_conv_f32_flip": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "snws_conv_f32_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    "snws_conv_f32_wgrad_workspace_bytes": (c_int64, [POINTER(ConvDesc)]),
+    "snws_conv_f32_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_int64, P]),
     "snws_sn_ctx_floats": (c_int64, [c_int, c_int]),
     "snws_sn_ctxb_floats": (c_int64, [c_int, c_int]),
     "snws_sn_stats_tiles": (c_int, [c_int, c_int64, c_int]),
@@ -95,7 +101,7 @@ _SIGNATURES = {
 # entry points that return a status code (the others return a value)
 _STATUS = {k for k, (res, _) in _SIGNATURES.items() if res is c_int} - {
     "snws_version", "snws_conv_out_size", "snws_conv_mfma_tiles", "snws_sn_stats_tiles", "snws_ce_blocks",
-    "snws_upconv_stat_tiles", "snws_tile_minmax_blocks"}
+    "snws_upconv_stat_tiles", "snws_tile_minmax_blocks", "snws_conv_f32_tiles"}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -246,12 +246,22 @@ class PreparedWeight:
             self.pack_fwd = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=dev)
             nbytes = L.lib().snws_conv_pack_bytes(cfg.O, cfg.I, cfg.kh, cfg.kw)
             self.pack_dgrad = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=dev)
+        self._flipped = None
         if standardize:
             L.call("snws_ws_fwd", _ptr(w), cfg.O, cfg.Ig, cfg.kh, cfg.kw, None, _ptr(self.ohwi), _ptr(self.pack_fwd),
                    _ptr(self.pack_dgrad), _stream())
         else:
             L.call("snws_conv_pack", _ptr(w), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _ptr(self.ohwi), _ptr(self.pack_fwd),
                    _ptr(self.pack_dgrad), _stream())
+
+    def flipped(self):
+        """The float32 filter of the dgrad convolution, (I, kh, kw, O) with both spatial axes reversed (built on first
+        use for this weight version; the float32 MFMA tier reads it)."""
+        if self._flipped is None:
+            cfg = self.cfg
+            self._flipped = torch.empty((cfg.Ig, cfg.kh, cfg.kw, cfg.O), dtype=torch.float32, device=self.ohwi.device)
+            L.call("snws_conv_f32_flip", _ptr(self.ohwi), _ptr(self._flipped), cfg.O, cfg.Ig, cfg.kh, cfg.kw, _stream())
+        return self._flipped
 
 
 def _pad_channels(x, ld, c_to):
@@ -291,6 +301,16 @@ def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
                     ctypes.byref(d), _ptr(xs), _ptr(prep.pack_fwd), _ptr(b32), _ptr(y), _ptr(stat), _stream())
         except L.SnwsUnsupported:
             use_mfma, stat = False, None
+    if not use_mfma and F32_MFMA and not force_direct and x.dtype == torch.float32 and cfg.mfma_shape_ok():
+        # float32 tier on the f32 matrix instruction (exact f32 arithmetic, any channel counts)
+        y = new_nhwc(N, cfg.O, OH, OW, x.dtype, x.device)
+        if want_stats:
+            stat = torch.empty((N, L.lib().snws_conv_f32_tiles(H, W), cfg.O, 2), dtype=torch.float32, device=x.device)
+        d = cfg.desc(N, H, W, C, ldx, cfg.O)
+        flops = 2.0 * N * OH * OW * cfg.O * cfg.I * cfg.kh * cfg.kw
+        _launch("conv_f32_fwd_k%d" % cfg.kh, flops, "snws_conv_f32_fwd", ctypes.byref(d), _ptr(xs), _ptr(prep.ohwi), _ptr(b32),
+                _ptr(y), _ptr(stat), _stream())
+        use_mfma = "f32"
     if not use_mfma:
         y = new_nhwc(N, cfg.O, OH, OW, x.dtype, x.device)
         d = cfg.desc(N, H, W, C, ldx, cfg.O)
@@ -303,6 +323,11 @@ def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
 # of float atomics: two runs of the same step give bit-identical gradients.  SNWS_WGRAD_ATOMIC=1 selects the atomic
 # flush (A/B measurements).
 WGRAD_DETERMINISTIC = os.environ.get("SNWS_WGRAD_ATOMIC", "0") != "1"
+
+
+# float32 activations run the f32 matrix-instruction kernels (snws_conv_f32_*) for stride-1 3x3 / 1x1 convolutions;
+# SNWS_F32_MFMA=0 sends them to the direct (scalar FMA) kernels instead (A/B measurements).
+F32_MFMA = os.environ.get("SNWS_F32_MFMA", "1") != "0"
 
 
 # SwitchNorm-backward fusion.  A fused block tags its output with the SwitchNorm state it saved for backward
@@ -384,9 +409,14 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=N
     dev = dys.device
     c_run = xs.shape[1]
     dx = dw = db = None
-    if need_dx:
+    if need_dx and used_mfma == "f32" and dys.dtype == torch.float32:
+        dx = new_nhwc(N, C, H, W, dys.dtype, dev)
+        d = cfg.desc(N, H, W, C, C, lddy)
+        _launch("conv_f32_dgrad_k%d" % cfg.kh, 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw, "snws_conv_f32_dgrad",
+                ctypes.byref(d), _ptr(dys), _ptr(prep.flipped()), _ptr(dx), _stream())
+    elif need_dx:
         done = False
-        if used_mfma and cfg.O % 16 == 0 and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
+        if used_mfma is True and cfg.O % 16 == 0 and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
             dxp = new_nhwc(N, c_run, H, W, dys.dtype, dev)
             d = cfg.desc(N, H, W, c_run, c_run, lddy)
             try:
@@ -413,7 +443,15 @@ def _conv_backward_weights(dys, lddy, prep, saved, weight, need_dw, need_db, bia
     done = False
     if need_db:
         db = grad_out(bias_key, (cfg.O,), dev, zero=True, acc_ok=True)    # the wgrad kernels add to it
-    if used_mfma and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
+    if used_mfma == "f32" and dys.dtype == torch.float32:
+        d = cfg.desc(N, H, W, C, ldx, lddy)
+        ws_bytes = L.lib().snws_conv_f32_wgrad_workspace_bytes(ctypes.byref(d))
+        g = torch.empty((cfg.O, cfg.kh, cfg.kw, cfg.Ig), dtype=torch.float32, device=dev)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        _launch("conv_f32_wgrad_k%d" % cfg.kh, 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw, "snws_conv_f32_wgrad",
+                ctypes.byref(d), _ptr(xs), _ptr(dys), _ptr(g), _ptr(db), _ptr(ws), ws_bytes, _stream())
+        ldg, done = cfg.Ig, True
+    elif used_mfma is True and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
         d = cfg.desc(N, H, W, c_run, ldx, lddy)
         flops = 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw
         ws_bytes = L.lib().snws_conv_mfma_wgrad_workspace_bytes(ctypes.byref(d)) if WGRAD_DETERMINISTIC else -1
