@@ -241,6 +241,30 @@ int snws_sn_apply_noalloc(const void* x, int64_t ldx, void* y, int64_t ldy, cons
                           float* running_mean, float* running_var, int N, int64_t HW, int C, float eps, float momentum,
                           int training, int using_movavg, int using_bn, int relu, void* stream);
 
+/* The last block of the network fused with the classification head - SwitchNorm + ReLU of the final convolution
+ * (modeling/snorm.py:41-81, modeling/UNet3p_SNws.py:29-33) followed by the 1x1 nn.Conv2d head
+ * (modeling/UNet3p_SNws.py:93,158; modeling/UNet_SNws.py:93,151) and their autograd - without storing the normalised
+ * activation or its gradient.  bf16, C = 64 or 320 (SNWS_ERR_UNSUPPORTED otherwise: run the unfused entry points),
+ * at most 16 classes.  head_w: bf16 (16, C), rows >= n_class zero; head_b: f32 (16) or NULL; logits / dlogits: bf16
+ * (N*HW, 16), pixel stride 16, channels >= n_class of dlogits zero.
+ *   snws_sn_apply_head:       logits = head_w * act((x - ctx.mean) * ctx.scale + beta) + head_b   (ctx from snws_sn_mix_b)
+ *   snws_sn_head_bwd_reduce:  pass 1 of the SwitchNorm backward with dy = head_w^T * dlogits rebuilt on the fly:
+ *                             part [N][T][C][2], T = snws_sn_head_tiles(HW, C, 1), as snws_sn_bwd_mix_a takes it; plus the
+ *                             head's gradient as per-wave partials hw_part [N*T][16][C] and hb_part [N*T][16]: sum them
+ *                             with snws_partial_sum (fixed order: bit-reproducible)
+ *   snws_sn_head_bwd_apply:   pass 2: dx = A * dy' + B * x + K (ctxb from snws_sn_bwd_mix_b), dy' rebuilt the same way
+ *   snws_partial_sum:         out[i] (+)= sum_p part[p * len + i] */
+int snws_sn_head_tiles(int64_t HW, int C, int backward);
+int snws_sn_apply_head(const void* x, int64_t ldx, const float* ctx, const float* beta, const void* head_w,
+                       const float* head_b, void* logits, int N, int64_t HW, int C, int relu, void* stream);
+int snws_sn_head_bwd_reduce(const void* dlogits, const void* x, int64_t ldx, const float* ctx, const float* beta,
+                            const void* head_w, float* part, float* hw_part, float* hb_part, int N, int64_t HW, int C,
+                            int relu, void* stream);
+int snws_sn_head_bwd_apply(const void* dlogits, const void* x, int64_t ldx, const float* ctx, const float* ctxb,
+                           const float* beta, const void* head_w, void* dx, int64_t lddx, int N, int64_t HW, int C,
+                           int relu, void* stream);
+int snws_partial_sum(const float* part, int n_parts, int len, float* out, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batch normalisation on the same streaming kernels - replaces nn.BatchNorm2d (+ nn.ReLU) of the OCR head
  * (modeling/UNet3p_res_ocr_SNws.py:52-79,124,257,263) and _SynchronizedBatchNorm's statistics

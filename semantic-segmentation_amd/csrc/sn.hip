@@ -8,6 +8,7 @@
 // Moments are accumulated as sums of (x - shift) and (x - shift)^2 per tile in f32 and combined across tiles in
 // f64, in a fixed order, so results are bit-reproducible run to run.
 #include "common.h"
+#include "sn_ctx.h"
 
 namespace {
 
@@ -34,27 +35,6 @@ inline int sn_tiles(int N, int64_t HW, int C) {
   if (T < 1) T = 1;
   int64_t PT = cdiv64(HW, T);
   return (int)cdiv64(HW, PT);
-}
-
-// ctx layout (floats)
-struct CtxOff {
-  int64_t mean_in, var_in, mean, rstd, scale, ln, bn, total;
-};
-__host__ __device__ inline CtxOff ctx_off(int N, int C) {
-  CtxOff o;
-  int64_t NC = (int64_t)N * C;
-  o.mean_in = 0; o.var_in = NC; o.mean = 2 * NC; o.rstd = 3 * NC; o.scale = 4 * NC;
-  o.ln = 5 * NC; o.bn = 5 * NC + 2 * N; o.total = 5 * NC + 2 * N + 2 * C;
-  return o;
-}
-struct CtxbOff {
-  int64_t P, Q, dm, dv, B, K, lnb, total;
-};
-__host__ __device__ inline CtxbOff ctxb_off(int N, int C) {
-  CtxbOff o;
-  int64_t NC = (int64_t)N * C;
-  o.P = 0; o.Q = NC; o.dm = 2 * NC; o.dv = 3 * NC; o.B = 4 * NC; o.K = 5 * NC; o.lnb = 6 * NC; o.total = 6 * NC + 2 * N;
-  return o;
 }
 
 // ------------------------------------------------------------------------------------------- pass 1: moments

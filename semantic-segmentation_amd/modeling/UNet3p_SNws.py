@@ -7,7 +7,7 @@ The seven decoder blocks are shared by the four decoder scales, as in the refere
 import torch
 import torch.nn as nn
 
-from modeling.blocks import ConvSnRelu, PoolPyramid, full_scale_decoder, head_conv, to_device_layout
+from modeling.blocks import ConvSnRelu, PoolPyramid, finish_logits, full_scale_decoder, head_conv, to_device_layout
 from snws import ops
 
 
@@ -43,4 +43,8 @@ class UNet3p_SNws(nn.Module):
                 t = pools.get(lvl - 1, 2)       # shared with the decoder's factor-2 skip of the same map
             t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
             enc[lvl] = t
-        return head_conv(self.output_seg_map, full_scale_decoder(self, enc, pools), raw=self.raw_logits)
+        # the last fusion block and the classification head run as one fused op when they can (bf16, 64 / 320 channels)
+        out, fused = full_scale_decoder(self, enc, pools, head=self.output_seg_map)
+        if fused:
+            return finish_logits(out, self.output_seg_map.out_channels, raw=self.raw_logits)
+        return head_conv(self.output_seg_map, out, raw=self.raw_logits)

@@ -4,7 +4,7 @@ ConvSnRelu block and the resample kernels."""
 import torch
 import torch.nn as nn
 
-from modeling.blocks import ConvSnRelu, crop_concat, head_conv, to_device_layout
+from modeling.blocks import ConvSnRelu, crop_concat, finish_logits, head_conv, to_device_layout
 from snws import ops
 
 
@@ -41,5 +41,10 @@ class UNet_SNws(nn.Module):
         for (up1, c2, c3) in ((self.conv_u1, self.conv_u2, self.conv_u3), (self.conv5_1, self.conv5_2, self.conv5_3),
                               (self.conv6_1, self.conv6_2, self.conv6_3), (self.conv7_1, self.conv7_2, self.conv7_3)):
             x = up1.on_upsampled(x, 2)       # 1x1 conv of the x2 up-sampled map, computed at low resolution
-            x = c3(c2(crop_concat(skips.pop(), x)))
+            x = c2(crop_concat(skips.pop(), x))
+            if c3 is self.conv7_3 and c3.head_fusable(x, self.output_seg_map):
+                # the last block and the classification head as one fused op (bf16 tier, 64 channels)
+                return finish_logits(c3.with_head(x, self.output_seg_map), self.output_seg_map.out_channels,
+                                     raw=self.raw_logits)
+            x = c3(x)
         return head_conv(self.output_seg_map, x, raw=self.raw_logits)

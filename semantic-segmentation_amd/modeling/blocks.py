@@ -40,6 +40,20 @@ class ConvSnRelu(nn.Sequential):
                                                         True, out))
 
 
+    def with_head(self, x, head):
+        """head(self(x)) for a 1x1 nn.Conv2d classification head as ONE fused op (no normalised activation, no
+        gradient of it, ever stored): the raw logits (N, 16, H, W) bf16, channels >= head.out_channels are padding.
+        Call only when ops.head_fusable(x, cfg, head)."""
+        conv, norm = self[0], self[1]
+        prep = conv.prepared(True)
+        return ops.ConvSnReluHeadFn.apply(x, conv.weight, conv.bias, norm.weight, norm.bias, norm.mean_weight,
+                                          norm.var_weight, head.weight, head.bias, prep, ops.SNParams(norm))
+
+    def head_fusable(self, x, head):
+        conv = self[0]
+        cfg = ops.ConvCfg(conv.weight.shape, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return (not conv.force_direct) and x.dim() == 4 and x.is_cuda and ops.head_fusable(x, cfg, head)
+
     # ---- the block applied to nn.Upsample(scale_factor=k, mode='bilinear')(x), without building the up-sampled map
     def taps(self, x):
         """Z = W_taps x at x's resolution; feed it to up(Z, k) for every scale k that needs conv(upsample_k(x))."""
@@ -103,6 +117,12 @@ def head_conv(conv, x, raw=False):
     if raw:
         return plain_conv(conv, x, raw=True)
     return plain_conv(conv, x).float()
+
+
+def finish_logits(raw16, n_class, raw=False):
+    """What head_conv returns, from the fused op's raw logits (N, 16, H, W): as they are (raw=True) or the n_class
+    real channels as float32."""
+    return raw16 if raw else raw16[:, :n_class].float()
 
 
 class PlainConv2d(nn.Conv2d):
@@ -192,10 +212,11 @@ class PoolPyramid:
         return self.maps[key]
 
 
-def full_scale_decoder(m, enc, pools=None):
+def full_scale_decoder(m, enc, pools=None, head=None):
     """The UNet3+ full-scale skip decoder (modeling/UNet3p_SNws.py:127-156, UNet3p_res_ocr_SNws.py:327-361) over
     the encoder maps enc[1..5]; m holds convd{1..4}_cat, conv5_cat, convu_cat, conv_fusion.  Returns the finest
-    decoder map.  Every up-sampled source goes through conv(upsample(x)) = sum_t up(W_t x): the 1x1 half
+    decoder map - or, with `head` (the 1x1 classification conv that consumes it), (raw logits, True) when the last
+    fusion block and the head can run as one fused op, else (finest decoder map, False).  Every up-sampled source goes through conv(upsample(x)) = sum_t up(W_t x): the 1x1 half
     Z = W_taps x is computed once per source at ITS resolution and shared by all the scales that consume it."""
     enc_cat = {1: m.convd1_cat, 2: m.convd2_cat, 3: m.convd3_cat, 4: m.convd4_cat}
     if pools is None:
@@ -224,5 +245,10 @@ def full_scale_decoder(m, enc, pools=None):
                     parts.append(m.convu_cat.up(zdec[src], 2 ** (src - level), out=out))
             # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
             parts.append(m.conv5_cat.up(z5, 2 ** (5 - level), out=buf[:, 4 * f:5 * f]))
-        dec[level] = m.conv_fusion(ops.assemble(buf, parts))
+        fused_in = ops.assemble(buf, parts)
+        if level == 1 and head is not None:
+            if m.conv_fusion.head_fusable(fused_in, head):
+                return m.conv_fusion.with_head(fused_in, head), True
+            return m.conv_fusion(fused_in), False
+        dec[level] = m.conv_fusion(fused_in)
     return dec[1]

@@ -652,9 +652,10 @@ def _f32c(t):
     return (t if t.dtype == torch.float32 else t.float()).contiguous()
 
 
-def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=None):
+def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=None, apply=True):
     """SwitchNorm (+ReLU) of the logical (N,C,H,W) tensor x.  stat_part/stat_shift: partial moments from the
-    conv epilogue (then x is not re-read for statistics).  Returns (y, saved)."""
+    conv epilogue (then x is not re-read for statistics).  Returns (y, saved).  apply=False stops after the
+    coefficients (saved["ctx"]): the caller runs its own normalise pass (the fused classification head); y is None."""
     require_gpu(x, "SwitchNorm2d")
     N, C, H, W = x.shape
     HW = H * W
@@ -677,7 +678,7 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     L.call("snws_sn_finalize", _ptr(stat_part), T, _ptr(stat_shift), per_image, N, HW, C, _ptr(ctx), st)
     synced = p.sync and p.training and p.using_bn and dp_collectives(p.group)
     world = sync_world(p.group) if synced else 1
-    batch = STAT_BATCH if (synced and STAT_BATCH is not None and STAT_BATCH.group is p.group) else None
+    batch = STAT_BATCH if (apply and synced and STAT_BATCH is not None and STAT_BATCH.group is p.group) else None
     pack = batch.slot(2 * C + 1, dev) if batch is not None else torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
     L.call("snws_sn_mix_a", _ptr(ctx), _ptr(pack), N, C, st)
     if synced and batch is None:
@@ -688,7 +689,9 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     rv = p.running_var.view(-1) if p.using_bn else None
     if p.using_bn and (rm.dtype != torch.float32 or not rm.is_contiguous() or rv.dtype != torch.float32):
         raise TypeError("SwitchNorm2d running buffers must be contiguous float32")
-    if out is None:
+    if not apply:
+        y, ldy = None, 0
+    elif out is None:
         y, ldy = new_nhwc(N, C, H, W, x.dtype, dev), C
     else:       # caller-provided destination, e.g. a channel slice of a concat buffer
         if tuple(out.shape) != (N, C, H, W) or out.dtype != x.dtype:
@@ -705,8 +708,9 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     def finish():       # everything after the (possibly shared) statistics all-reduce
         L.call("snws_sn_mix_b", _ptr(ctx), _ptr(pack), _ptr(gamma), _ptr(mw), _ptr(vw), _ptr(rm), _ptr(rv), N, C,
                eps, momentum, training, movavg, using_bn, st)
-        _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), ldy, _ptr(rs),
-                ldr, dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
+        if apply:
+            _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), ldy, _ptr(rs),
+                    ldr, dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
     if batch is not None:
         batch.pending.append(finish)      # y is filled when the batch is flushed
     else:
@@ -718,7 +722,7 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     return y, saved
 
 
-def sn_backward_pass1(dy, s, packb=None):
+def sn_backward_pass1(dy, s, packb=None, partials=None):
     """First half of the SwitchNorm backward, up to the payload of the backward all-reduce: the two reductions per
     (n, c) (or the partial sums a consumer's dgrad epilogue left), d gamma / d beta, and packb = [sum_n dm, sum_n dv]
     (written into `packb` when given - a slot of a buffer shared by several layers).  Returns the state
@@ -728,15 +732,22 @@ def sn_backward_pass1(dy, s, packb=None):
     HW = H * W
     lib = L.lib()
     st = _stream()
-    dys, lddy = as_nhwc(dy)
-    if dys.dtype != s["xs"].dtype:
-        dys, lddy = as_nhwc(dy.to(s["xs"].dtype))
-    dt = dtype_code(dys)
-    dev = dys.device
-    ym = s["y"]
-    yms, ldym = (None, 0) if ym is None else as_nhwc(ym)
-    fused = fused_bwd_partials(s, dys, lddy) if ym is None else None
-    if fused is not None:
+    if partials is not None:
+        # (part, T) computed by the caller (the fused classification head rebuilds dy on the fly): dy may be None
+        part, T = partials
+        dys, lddy, yms, ldym, dev = None, 0, None, 0, part.device
+    else:
+        dys, lddy = as_nhwc(dy)
+        if dys.dtype != s["xs"].dtype:
+            dys, lddy = as_nhwc(dy.to(s["xs"].dtype))
+        dt = dtype_code(dys)
+        dev = dys.device
+        ym = s["y"]
+        yms, ldym = (None, 0) if ym is None else as_nhwc(ym)
+    fused = fused_bwd_partials(s, dys, lddy) if (partials is None and ym is None) else None
+    if partials is not None:
+        pass
+    elif fused is not None:
         part, T = fused
     else:
         T = lib.snws_sn_stats_tiles(N, HW, C)
@@ -754,19 +765,19 @@ def sn_backward_pass1(dy, s, packb=None):
         raise RuntimeError("SwitchNorm weight and bias must be used together")
     L.call("snws_sn_bwd_mix_a", _ptr(part), T, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(ctxb), _ptr(packb), _ptr(dgamma),
            _ptr(dbeta), N, C, int(acc_a), st)
-    return dict(dys=dys, lddy=lddy, yms=yms, ldym=ldym, ctxb=ctxb, packb=packb, dgamma=dgamma, dbeta=dbeta,
-                key=(dy.data_ptr(), tuple(dy.shape), tuple(dy.stride()), dy._version))
+    return dict(dys=dys, lddy=lddy, yms=yms, ldym=ldym, ctxb=ctxb, packb=packb, dgamma=dgamma, dbeta=dbeta, dev=dev,
+                key=None if dy is None else (dy.data_ptr(), tuple(dy.shape), tuple(dy.stride()), dy._version))
 
 
-def sn_backward_pass2(s, p1, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
-    """Second half: coefficients from the (all-reduced) packb, d mean_weight / d var_weight, the apply pass."""
+def sn_backward_pass2(s, p1, want_dx_sum=False, dx_sum_key=None, dres_dtype=None, apply_fn=None):
+    """Second half: coefficients from the (all-reduced) packb, d mean_weight / d var_weight, the apply pass (or
+    apply_fn(ctxb) -> dx in its place)."""
     N, C, H, W = s["shape"]
     HW = H * W
     st = _stream()
     dys, lddy, yms, ldym, ctxb, packb = p1["dys"], p1["lddy"], p1["yms"], p1["ldym"], p1["ctxb"], p1["packb"]
     dgamma, dbeta = p1["dgamma"], p1["dbeta"]
-    dt = dtype_code(dys)
-    dev = dys.device
+    dev = p1["dev"]
     K = s["mw"].numel()
     dmw = grad_out(grad_key(s["mw"]), (K,), dev, acc_ok=True)
     dvw = grad_out(grad_key(s["vw"]), (K,), dev, acc_ok=True)
@@ -776,6 +787,10 @@ def sn_backward_pass2(s, p1, want_dx_sum=False, dx_sum_key=None, dres_dtype=None
     acc_b = int(grad_accumulates(dmw)) | (2 if dxsum is not None and grad_accumulates(dxsum) else 0)
     L.call("snws_sn_bwd_mix_b", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), _ptr(s["mw"]), _ptr(s["vw"]), None, None,
            _ptr(dmw), _ptr(dvw), _ptr(dxsum), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), acc_b, st)
+    if apply_fn is not None:
+        dx = apply_fn(ctxb)
+        return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw)
+    dt = dtype_code(dys)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
     if dres_dtype is not None and dres_dtype == dys.dtype and yms is not None and s["relu"]:
         dres = s["dres"] = new_nhwc(N, C, H, W, dys.dtype, dev)
@@ -1053,6 +1068,97 @@ class ConvSnReluFn(torch.autograd.Function):
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, None, None, None, None
+
+
+HEAD_FUSION = os.environ.get("SNWS_HEAD_FUSION", "1") != "0"
+
+
+def head_fusable(x, conv_cfg, head):
+    """Can ConvSnRelu + the 1x1 classification head run as the fused op?  bf16 MFMA path, 64 or 320 channels into a
+    bias-or-not 1x1 stride-1 nn.Conv2d with at most 16 classes."""
+    return HEAD_FUSION and x.dtype == torch.bfloat16 and conv_cfg.mfma_shape_ok() and conv_cfg.O in (64, 320) and \
+        tuple(head.kernel_size) == (1, 1) and tuple(head.stride) == (1, 1) and tuple(head.padding) == (0, 0) and \
+        head.groups == 1 and head.in_channels == conv_cfg.O and head.out_channels <= 16
+
+
+class ConvSnReluHeadFn(torch.autograd.Function):
+    """ConvSnRelu (modeling/UNet3p_SNws.py:29-33) followed by the 1x1 classification head
+    (modeling/UNet3p_SNws.py:93,158) as one op that never stores the normalised activation or its gradient: the
+    SwitchNorm apply pass multiplies by the head filter on the fly, and the backward passes rebuild
+    W_head^T * dlogits where they need it.  Returns the raw logits (N, 16, H, W) bf16 channels-last; channels
+    >= n_class are padding."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, mean_weight, var_weight, head_w, head_b, prep, p):
+        conv_out, stat, saved = conv_forward(x, prep, bias, want_stats=True)
+        if saved[3] is not True or stat is None:
+            raise RuntimeError("ConvSnReluHeadFn needs the bf16 MFMA convolution path")
+        shift = _f32c(bias) if bias is not None else torch.zeros(weight.shape[0], dtype=torch.float32, device=x.device)
+        _, sn = sn_forward(conv_out, p, True, stat_part=stat, stat_shift=shift, apply=False)
+        N, C, H, W = conv_out.shape
+        ncls = head_w.shape[0]
+        hw16 = torch.zeros((16, C), dtype=torch.bfloat16, device=x.device)
+        hw16[:ncls] = head_w.detach().reshape(ncls, C)
+        hb16 = None
+        if head_b is not None:
+            hb16 = torch.zeros(16, dtype=torch.float32, device=x.device)
+            hb16[:ncls] = head_b.detach()
+        logits = new_nhwc(N, 16, H, W, torch.bfloat16, x.device)
+        _launch("sn_apply_head", 2.0 * N * H * W * (C + 16), "snws_sn_apply_head", _ptr(sn["xs"]), sn["ldx"], _ptr(sn["ctx"]),
+                _ptr(sn["beta"]), _ptr(hw16), _ptr(hb16), _ptr(logits), N, H * W, C, 1, _stream())
+        ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn, bias is not None
+        ctx.bias_key, ctx.in_segs = grad_key(bias), input_segments(x)
+        ctx.shapes = (gamma.shape, beta.shape)
+        ctx.hw16, ctx.ncls, ctx.head_keys = hw16, ncls, (grad_key(head_w), grad_key(head_b))
+        ctx.head_shape, ctx.has_head_bias = tuple(head_w.shape), head_b is not None
+        ctx.save_for_backward(weight)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        (weight,) = ctx.saved_tensors
+        s = ctx.sn
+        N, C, H, W = s["shape"]
+        HW = H * W
+        lib, st, dev = L.lib(), _stream(), dl.device
+        dls, lddl = as_nhwc(dl if dl.dtype == torch.bfloat16 else dl.to(torch.bfloat16))
+        if lddl != 16 or dls.data_ptr() % 16:
+            dls = dls.contiguous(memory_format=torch.channels_last).clone(memory_format=torch.channels_last)
+        T = lib.snws_sn_head_tiles(HW, C, 1)
+        part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
+        hwp = torch.empty((N * T, 16, C), dtype=torch.float32, device=dev)
+        hbp = torch.empty((N * T, 16), dtype=torch.float32, device=dev)
+        _launch("sn_head_bwd_reduce", 2.0 * N * HW * (C + 16), "snws_sn_head_bwd_reduce", _ptr(dls), _ptr(s["xs"]), s["ldx"],
+                _ptr(s["ctx"]), _ptr(s["beta"]), _ptr(ctx.hw16), _ptr(part), _ptr(hwp), _ptr(hbp), N, HW, C, 1, st)
+        # the head's own gradients: fixed-order sums of the per-wave partials
+        dhw = dhb = None
+        if ctx.needs_input_grad[7]:
+            tmp = torch.empty((16, C), dtype=torch.float32, device=dev)
+            L.call("snws_partial_sum", _ptr(hwp), N * T, 16 * C, _ptr(tmp), 0, st)
+            dhw = tmp[:ctx.ncls].reshape(ctx.head_shape)
+        if ctx.has_head_bias and ctx.needs_input_grad[8]:
+            tmpb = torch.empty(16, dtype=torch.float32, device=dev)
+            L.call("snws_partial_sum", _ptr(hbp), N * T, 16, _ptr(tmpb), 0, st)
+            dhb = tmpb[:ctx.ncls]
+        p1 = sn_backward_pass1(None, s, partials=(part, T))
+        if s["synced"]:
+            _allreduce_sum(p1["packb"], s["group"])
+        xs, ldx, hw16 = s["xs"], s["ldx"], ctx.hw16
+
+        def apply_fn(ctxb):
+            dx = new_nhwc(N, C, H, W, torch.bfloat16, dev)
+            _launch("sn_head_bwd_apply", 2.0 * N * HW * (2 * C + 16), "snws_sn_head_bwd_apply", _ptr(dls), _ptr(xs), ldx,
+                    _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), _ptr(hw16), _ptr(dx), C, N, HW, C, 1, st)
+            return dx
+        dconv, dg, dbeta, dmw, dvw = sn_backward_pass2(s, p1, apply_fn=apply_fn)
+        ctx.sn = None
+        nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
+        ctx.in_segs = None
+        ctx.saved = None
+        if dw is not None:
+            dw = dw.to(weight.dtype)
+        return dx, dw, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, dhw, dhb, None, None
 
 
 class ConvSnAddReluFn(torch.autograd.Function):
