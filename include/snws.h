@@ -241,6 +241,16 @@ int snws_sn_apply_noalloc(const void* x, int64_t ldx, void* y, int64_t ldy, cons
                           float* running_mean, float* running_var, int N, int64_t HW, int C, float eps, float momentum,
                           int training, int using_movavg, int using_bn, int relu, void* stream);
 
+/* Wide 1x1 convolution of an NHWC bf16 tensor as one GEMM on the matrix cores: y[m][n] = sum_k x[m][k] * w[n][k] + bias[n]
+ * over all M = N*H*W pixels - the plain nn.Conv2d 1x1 layers of the OCR head (modeling/UNet3p_res_ocr_SNws.py:39-73,
+ * 118-123,269-274: F.conv2d with a (C_out, C_in, 1, 1) filter), their input gradient (the same product with w = the
+ * transposed filter), and the 1x1 half of conv(upsample(x)) (modeling/UNet3p_SNws.py:127-156).  w: bf16 [N][K] row-major;
+ * bias: f32 [N] or NULL; x / y: pixel strides ldx >= K / ldy >= N (multiples of 8).  snws_gemm1x1_supported(N, K): N >= 64
+ * and a multiple of 8, K a multiple of 64; other shapes return SNWS_ERR_UNSUPPORTED (use snws_conv_mfma_fwd). */
+int snws_gemm1x1_supported(int N, int K);
+int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M, int N, int K,
+                 void* stream);
+
 /* The last block of the network fused with the classification head - SwitchNorm + ReLU of the final convolution
  * (modeling/snorm.py:41-81, modeling/UNet3p_SNws.py:29-33) followed by the 1x1 nn.Conv2d head
  * (modeling/UNet3p_SNws.py:93,158; modeling/UNet_SNws.py:93,151) and their autograd - without storing the normalised

@@ -944,11 +944,31 @@ class Conv2dwsFn(torch.autograd.Function):
 GEMM_1X1 = os.environ.get("SNWS_CONV1X1_GEMM", "1") != "0"
 
 
+def gemm1x1_ok(n_out, n_in):
+    """Does the wide 1x1 kernel (snws_gemm1x1) take a product with n_out output and n_in contracted channels?"""
+    return GEMM_1X1 and bool(L.lib().snws_gemm1x1_supported(int(n_out), int(n_in)))
+
+
+def gemm1x1(x, w2d, bias=None, tag="gemm1x1_fwd"):
+    """y[n, :, h, w] = w2d @ x[n, :, h, w] (+ bias) for a logical (N, K, H, W) bf16 tensor x with channels-last storage
+    (a channel slice of a wider buffer is fine) and a bf16 (C_out, K) matrix; returns the (N, C_out, H, W) result."""
+    N, K, H, W = x.shape
+    xs, ldx = as_nhwc(x)
+    if ldx % 8 or xs.data_ptr() % 16:
+        xs, ldx = _pad_channels(xs, ldx, K)
+    n_out = w2d.shape[0]
+    y = new_nhwc(N, n_out, H, W, torch.bfloat16, x.device)
+    b32 = None if bias is None else (bias.detach() if bias.dtype == torch.float32 else bias.detach().float())
+    _launch(tag, 2.0 * N * H * W * n_out * K, "snws_gemm1x1", _ptr(xs), ldx, _ptr(w2d), _ptr(b32), _ptr(y), n_out,
+            N * H * W, n_out, K, _stream())
+    return y, xs, ldx
+
+
 def _gemm_1x1_ok(x, cfg):
     """Plain 1x1 convolutions wide enough (>= 128 channels both sides) that a 64-channel output tile would re-read
-    the pixels more than once."""
-    return GEMM_1X1 and cfg.kh == 1 and cfg.kw == 1 and x.dtype == torch.bfloat16 and x.is_cuda and \
-        cfg.I >= 128 and cfg.O >= 128 and cfg.I % 16 == 0 and cfg.O % 16 == 0
+    the pixels more than once: both the product and its input gradient run on snws_gemm1x1."""
+    return cfg.kh == 1 and cfg.kw == 1 and x.dtype == torch.bfloat16 and x.is_cuda and cfg.I >= 128 and cfg.O >= 128 and \
+        gemm1x1_ok(cfg.O, cfg.I) and gemm1x1_ok(cfg.I, cfg.O)
 
 
 class _PlainCfg:
@@ -968,27 +988,17 @@ class PlainConvFn(torch.autograd.Function):
         ctx.in_segs = input_segments(x)
         ctx.gemm_w = None
         if ctx.in_segs is None and _gemm_1x1_ok(x, cfg):
-            # a wide plain 1x1 convolution of a dense NHWC tensor IS a plain GEMM [pixels x C_in] x [C_in x C_out]:
-            # the vendor GEMM runs it (and its dgrad) 1.4-2x faster than the 64-channel-tile conv kernel, which re-stages
-            # the pixels once per 64 output channels; the weight gradient stays on snws_conv_mfma_wgrad (f32 result)
+            # a wide plain 1x1 convolution of an NHWC tensor IS a GEMM [pixels x C_in] x [C_in x C_out]: the wide-tile
+            # kernel stages the pixels once per 128-256 output channels instead of once per 64; the weight gradient
+            # stays on snws_conv_mfma_wgrad (f32 result)
             N, C, H, W = x.shape
-            xs, ldx = as_nhwc(x)
-            if ldx % 8 == 0 and xs.data_ptr() % 16 == 0:
-                wb = weight.detach().reshape(cfg.O, C).to(torch.bfloat16)
-                x2 = xs.permute(0, 2, 3, 1).reshape(N * H * W, C)
-                y = new_nhwc(N, cfg.O, H, W, x.dtype, x.device)
-                y2 = y.permute(0, 2, 3, 1).view(N * H * W, cfg.O)
-                flops = 2.0 * N * H * W * cfg.O * C
-                if bias is None:
-                    _timed("gemm_1x1_fwd", flops, lambda: torch.mm(x2, wb.t(), out=y2))
-                else:
-                    bb = bias.detach().to(torch.bfloat16)
-                    _timed("gemm_1x1_fwd", flops, lambda: torch.addmm(bb, x2, wb.t(), out=y2))
-                ctx.gemm_w = wb
-                ctx.prep = _PlainCfg(cfg)
-                ctx.saved, ctx.has_bias, ctx.bias_key = (xs, ldx, (N, C, H, W), True), bias is not None, grad_key(bias)
-                ctx.save_for_backward(weight)
-                return y
+            wb = weight.detach().reshape(cfg.O, C).to(torch.bfloat16)
+            y, xs, ldx = gemm1x1(x, wb, bias)
+            ctx.gemm_w = wb
+            ctx.prep = _PlainCfg(cfg)
+            ctx.saved, ctx.has_bias, ctx.bias_key = (xs, ldx, (N, C, H, W), True), bias is not None, grad_key(bias)
+            ctx.save_for_backward(weight)
+            return y
         prep = PreparedWeight(weight, cfg, x.dtype == torch.bfloat16, standardize=False)
         y, _, saved = conv_forward(x, prep, bias)
         ctx.prep, ctx.saved, ctx.has_bias, ctx.bias_key = prep, saved, bias is not None, grad_key(bias)
@@ -1004,10 +1014,8 @@ class PlainConvFn(torch.autograd.Function):
             dys, lddy = as_nhwc(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16))
             dx = dw = db = None
             if nx:
-                dx = new_nhwc(N, C, H, W, dys.dtype, dys.device)
-                dy2 = dys.permute(0, 2, 3, 1).reshape(N * H * W, wb.shape[0])
-                _timed("gemm_1x1_dgrad", 2.0 * N * H * W * wb.shape[0] * C,
-                       lambda: torch.mm(dy2, wb, out=dx.permute(0, 2, 3, 1).view(N * H * W, C)))
+                dx, dys, lddy = gemm1x1(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), wb.t().contiguous(),
+                                        None, tag="gemm1x1_dgrad")
             if nw or nb:
                 if lddy % 8 or dys.data_ptr() % 16:
                     dys = dys.contiguous(memory_format=torch.channels_last)
@@ -1214,6 +1222,10 @@ class PreparedTaps:
         self.cfg = cfg
         self.cfg_re = ConvCfg(wre.shape, 1, 0, 1, 1)
         self.prep = PreparedWeight(wre, self.cfg_re, want_mfma, standardize=False)
+        # the same filter as a plain (taps*O, I) bf16 matrix for the wide 1x1 kernel, when it takes the shape
+        self.gemm_w = None
+        if want_mfma and gemm1x1_ok(wre.shape[0], cfg.Ig):
+            self.gemm_w = wre.reshape(wre.shape[0], cfg.Ig).to(torch.bfloat16)
 
 
 class TapConvFn(torch.autograd.Function):
@@ -1222,7 +1234,11 @@ class TapConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, taps_prep):
-        z, _, saved = conv_forward(x, taps_prep.prep, None)
+        if taps_prep.gemm_w is not None and x.dtype == torch.bfloat16:
+            z, xs, ldx = gemm1x1(x, taps_prep.gemm_w, None, tag="gemm1x1_taps")
+            saved = (xs, ldx, tuple(x.shape), True)
+        else:
+            z, _, saved = conv_forward(x, taps_prep.prep, None)
         ctx.tp, ctx.saved, ctx.in_segs = taps_prep, saved, input_segments(x)
         ctx.save_for_backward(weight)
         return z

@@ -1632,8 +1632,8 @@ np.savez(sys.argv[1], **out)
 @pytest.mark.parametrize("cin,cout,with_bias,sliced", [(256, 128, True, False), (512, 256, False, False),
                                                        (128, 320, True, True)])
 def test_wide_plain_1x1_conv_gemm_route_matches_conv_kernel(cin, cout, with_bias, sliced):
-    """Plain 1x1 convolutions with >= 128 channels on both sides run forward and dgrad as a library GEMM over the NHWC
-    pixels; the result must equal the library's own MFMA conv kernel route (same bf16 operands, f32 accumulation)
+    """Plain 1x1 convolutions with >= 128 channels on both sides run forward and dgrad on the wide-tile 1x1 kernel
+    (snws_gemm1x1) over the NHWC pixels; the result must equal the library's 64-channel-tile MFMA conv kernel route (same bf16 operands, f32 accumulation)
     within the bf16 bar, and the float64 product within 2e-2.  `sliced`: the input is a channel slice of a wider
     NHWC buffer (pixel stride > C_in)."""
     from snws import ops
@@ -1658,7 +1658,7 @@ def test_wide_plain_1x1_conv_gemm_route_matches_conv_kernel(cin, cout, with_bias
             y.backward(dy)
             tags = {t[0] for t in ops.PROFILE}
             ops.PROFILE = None
-            assert ("gemm_1x1_fwd" in tags and "gemm_1x1_dgrad" in tags) == gemm, tags
+            assert ("gemm1x1_fwd" in tags and "gemm1x1_dgrad" in tags) == gemm, tags
             out[gemm] = (y.detach().float(), x.grad.float(), w.grad.float(), None if b is None else b.grad.float())
     finally:
         ops.GEMM_1X1 = prev
@@ -1677,6 +1677,49 @@ def test_wide_plain_1x1_conv_gemm_route_matches_conv_kernel(cin, cout, with_bias
     if with_bias:
         assert rel(out[True][3], dy.double().sum((0, 2, 3))) < 1e-4 and rel(out[True][3], out[False][3]) < 1e-5
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,ldx_extra,bias", [
+    (256, 256, 64, 0, False),          # one tile, one step
+    (1000, 320, 320, 0, True),         # ragged pixel tail, 160-wide channel tiles
+    (70000, 576, 128, 64, False),      # more tiles than workgroups (persistent loop), 192-wide tiles, strided input
+    (5000, 1024, 512, 0, True),        # four channel tiles per pixel tile
+    (513, 64, 1024, 0, True),          # narrowest output, deepest contraction
+    (3000, 72, 256, 0, True),          # channel count that is not a multiple of 16
+    (4096, 512, 256, 0, False),
+])
+def test_gemm1x1_kernel_vs_float64(M, N, K, ldx_extra, bias):
+    """snws_gemm1x1 through the C ABI against the float64 product of the same bf16 operands: every output within
+    half a bf16 step of the exact value plus f32 accumulation noise (relative L2 < 3e-3, worst element < 1e-2 of the
+    largest); rows past M and columns past N of the padded tiles are never written."""
+    import ctypes
+    from snws import _lib as L
+    torch.manual_seed(M + N + K)
+    ldx = K + ldx_extra
+    xbuf = torch.randn(M, ldx, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV) if bias else None
+    ldy = N + 8
+    y = torch.full((M + 3, ldy), 7.0, device=DEV, dtype=torch.bfloat16)
+    L.call("snws_gemm1x1", xbuf.data_ptr(), ldx, w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), ldy, M, N, K,
+           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ref = xbuf[:, :K].double() @ w.double().t() + (0 if b is None else b.double())
+    got = y[:M, :N].double()
+    assert float((got - ref).norm() / ref.norm()) < 3e-3
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-2
+    assert bool((y[M:] == 7.0).all()) and bool((y[:, N:] == 7.0).all())
+
+
+def test_gemm1x1_rejects_unsupported_shapes():
+    from snws import _lib as L
+    lib = L.lib()
+    assert lib.snws_gemm1x1_supported(320, 320) == 1 and lib.snws_gemm1x1_supported(576, 1024) == 1
+    assert lib.snws_gemm1x1_supported(16, 320) == 0 and lib.snws_gemm1x1_supported(320, 14) == 0
+    assert lib.snws_gemm1x1_supported(100, 64) == 0
+    x = torch.zeros(64, 96, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(L.SnwsUnsupported):
+        L.call("snws_gemm1x1", x.data_ptr(), 96, x.data_ptr(), None, x.data_ptr(), 96, 64, 64, 96, None)
 
 
 @pytest.mark.parametrize("arch", ["unet3p", "unet"])
