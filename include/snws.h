@@ -251,6 +251,32 @@ int snws_gemm1x1_supported(int N, int K);
 int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M, int N, int K,
                  void* stream);
 
+/* The two attention steps of the OCR head as fused streaming kernels (bf16 NHWC pixel tensors, float32 soft-max, every
+ * small product on the matrix cores; per-class results leave as per-wave partial rows to be summed with snws_partial_sum).
+ *   SpatialGather_Module.forward, modeling/UNet3p_res_ocr_SNws.py:21-28:
+ *     ctx[b][k][c] = sum_p softmax_p(scale * probs[b][p][k]) * feats[b][p][c]          (C = 512 feature channels, K <= 16)
+ *     snws_ocr_gather_stats: per-run (max, sum exp) pairs, stat_part [B][snws_ocr_tiles(HW, 0)][16][2]
+ *     snws_ocr_gather_fwd:   ctx_part [B][snws_ocr_tiles(HW, 1)][16][C]
+ *     snws_ocr_gather_bwd:   dfeats = P * dctx, dprobs = scale * P * (feats . dctx - dot), dot[b][k] = <ctx, dctx>;
+ *                            dctx bf16 [B][16][C] (rows >= K zero), dprobs bf16 [B][HW][16]
+ *   _ObjectAttentionBlock.forward, modeling/UNet3p_res_ocr_SNws.py:87-100 (between f_pixel / f_object / f_down and f_up):
+ *     out[b][p][c] = sum_k softmax_k(scale * q[b][p] . key[b][k]) * val[b][k][c]       (C = 256 key channels, K <= 16)
+ *     snws_ocr_attend_fwd; key / val: bf16 [B][16][C], rows >= K zero
+ *     snws_ocr_attend_bwd:   dq, and dkey_part / dval_part [B][snws_ocr_tiles(HW, 2)][16][C]
+ * Other channel counts return SNWS_ERR_UNSUPPORTED. */
+int snws_ocr_tiles(int64_t HW, int kind);
+int snws_ocr_gather_stats(const void* probs, int64_t ldp, float* stat_part, int B, int64_t HW, int K, float scale, void* stream);
+int snws_ocr_gather_fwd(const void* feats, int64_t ldf, const void* probs, int64_t ldp, const float* stat_part, float* ctx_part,
+                        int B, int64_t HW, int C, int K, float scale, void* stream);
+int snws_ocr_gather_bwd(const void* feats, int64_t ldf, const void* probs, int64_t ldp, const float* stat_part, const void* dctx,
+                        const float* dot, void* dfeats, int64_t lddf, void* dprobs, int B, int64_t HW, int C, int K, float scale,
+                        void* stream);
+int snws_ocr_attend_fwd(const void* q, int64_t ldq, const void* key, const void* val, void* out, int64_t ldo, int B, int64_t HW,
+                        int C, int K, float scale, void* stream);
+int snws_ocr_attend_bwd(const void* q, int64_t ldq, const void* dout, int64_t lddo, const void* key, const void* val, void* dq,
+                        int64_t lddq, float* dkey_part, float* dval_part, int B, int64_t HW, int C, int K, float scale,
+                        void* stream);
+
 /* The last block of the network fused with the classification head - SwitchNorm + ReLU of the final convolution
  * (modeling/snorm.py:41-81, modeling/UNet3p_SNws.py:29-33) followed by the 1x1 nn.Conv2d head
  * (modeling/UNet3p_SNws.py:93,158; modeling/UNet_SNws.py:93,151) and their autograd - without storing the normalised
@@ -274,6 +300,8 @@ int snws_sn_head_bwd_apply(const void* dlogits, const void* x, int64_t ldx, cons
                            const float* beta, const void* head_w, void* dx, int64_t lddx, int N, int64_t HW, int C,
                            int relu, void* stream);
 int snws_partial_sum(const float* part, int n_parts, int len, float* out, int accumulate, void* stream);
+/* the same for `batch` independent entries: part [batch][n_parts][len] -> out [batch][len] */
+int snws_partial_sum_batched(const float* part, int batch, int n_parts, int len, float* out, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batch normalisation on the same streaming kernels - replaces nn.BatchNorm2d (+ nn.ReLU) of the OCR head

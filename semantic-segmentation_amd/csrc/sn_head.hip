@@ -337,6 +337,8 @@ __global__ __launch_bounds__(512) void head_partial_sum_kernel(const float* __re
   __shared__ float red[7][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
+  part += (int64_t)blockIdx.y * nparts * len;       // batch entry
+  out += (int64_t)blockIdx.y * len;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < len) {
     const float* p = part + i;
@@ -436,8 +438,13 @@ extern "C" int snws_sn_head_bwd_apply(const void* dlogits, const void* x, int64_
 }
 
 extern "C" int snws_partial_sum(const float* part, int n_parts, int len, float* out, int accumulate, void* stream) {
-  SNWS_CHECK_ARG(part && out && n_parts >= 1 && len >= 1, "snws_partial_sum: bad arguments");
-  head_partial_sum_kernel<<<cdiv(len, 64), 512, 0, (hipStream_t)stream>>>(part, n_parts, len, out, accumulate);
+  return snws_partial_sum_batched(part, 1, n_parts, len, out, accumulate, stream);
+}
+
+extern "C" int snws_partial_sum_batched(const float* part, int batch, int n_parts, int len, float* out, int accumulate,
+                                        void* stream) {
+  SNWS_CHECK_ARG(part && out && batch >= 1 && batch <= 65535 && n_parts >= 1 && len >= 1, "snws_partial_sum: bad arguments");
+  head_partial_sum_kernel<<<dim3(cdiv(len, 64), batch), 512, 0, (hipStream_t)stream>>>(part, n_parts, len, out, accumulate);
   SNWS_LAUNCH_CHECK("snws_partial_sum");
   return SNWS_OK;
 }

@@ -5,8 +5,9 @@ shapes and registration order (a reference checkpoint loads with load_state_dict
 What runs where: every Conv2dws -> SwitchNorm2d -> ReLU block, the residual blocks' conv + SwitchNorm + add + ReLU,
 the full-scale skip decoder and all plain nn.Conv2d layers (1x1 and the 320 -> 512 3x3) go through the library's
 HIP kernels, and so do the OCR head's BatchNorm2d + ReLU pairs (blocks.HipBatchNorm2d; statistics of the local
-batch, as under the reference's DataParallel).  Its two soft-max + batched-matmul attention steps and Dropout2d are
-stock torch ops on the GPU (rocBLAS / elementwise), as plain library work.
+batch, as under the reference's DataParallel) and, in the bf16 tier, its two soft-max + batched-matmul attention
+steps (ops.OcrGatherFn / ops.OcrAttendFn).  Dropout2d is the stock torch op; the float32 tier's attention is stock
+torch too.
 """
 import torch
 import torch.nn as nn
@@ -39,6 +40,8 @@ class SpatialGather_Module(nn.Module):
 
     def forward(self, feats, probs):
         B, K = probs.size(0), probs.size(1)
+        if ops.ocr_gather_ok(feats, probs):
+            return ops.OcrGatherFn.apply(feats, probs, float(self.scale))               # B x C x K x 1
         p = F.softmax(self.scale * probs.float().reshape(B, K, -1), dim=2)              # B x K x HW
         ctx = torch.matmul(p.to(feats.dtype), _pixels(feats))                           # B x K x C
         return ctx.permute(0, 2, 1).unsqueeze(3)                                        # B x C x K x 1
@@ -67,7 +70,14 @@ class _ObjectAttentionBlock(nn.Module):
         if self.scale > 1:
             x = self.pool(x)
         proxy = proxy.contiguous(memory_format=torch.channels_last)
-        query = _pixels(self.f_pixel(x))                                                 # B x HW x key
+        q4 = self.f_pixel(x)
+        if ops.ocr_attend_ok(q4, proxy):
+            context = ops.OcrAttendFn.apply(q4, self.f_object(proxy), self.f_down(proxy), self.key_channels ** -.5)
+            context = self.f_up(context)
+            if self.scale > 1:
+                context = F.interpolate(input=context, size=(h, w), mode='bilinear', align_corners=True)
+            return context
+        query = _pixels(q4)                                                              # B x HW x key
         key = self.f_object(proxy).reshape(B, self.key_channels, -1)                     # B x key x K
         value = _pixels(self.f_down(proxy))                                              # B x K x key
         # attention logits in float32: a bf16 result would carry ~0.4 % of |logit| into the soft-max exponent

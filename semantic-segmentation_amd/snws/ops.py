@@ -1208,6 +1208,121 @@ class ConvSnAddReluFn(torch.autograd.Function):
         return dx, dw, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, None, None, dres
 
 
+# ------------------------------------------------------------------------------------------------ OCR attention
+OCR_KERNELS = os.environ.get("SNWS_OCR_KERNELS", "1") != "0"
+OCR_GATHER_C, OCR_ATTEND_C = 512, 256      # channel counts the fused kernels are built for
+
+
+def _rows16(t, K):
+    """(B, C, K, 1) class-major tensor -> dense bf16 (B, 16, C) matrix with rows >= K zero."""
+    B, C = t.shape[0], t.shape[1]
+    out = torch.zeros((B, 16, C), dtype=torch.bfloat16, device=t.device)
+    out[:, :K] = t.detach().permute(0, 2, 3, 1).reshape(B, K, C)
+    return out
+
+
+def _from_rows(m, K, dtype):
+    """(B, 16, C) -> logical (B, C, K, 1) with channels-last storage."""
+    B, _, C = m.shape
+    return m[:, :K].to(dtype).contiguous().view(B, K, 1, C).permute(0, 3, 1, 2)
+
+
+def _class_rows(probs):
+    """Class scores (B, K, H, W) as an NHWC tensor whose pixel rows hold at least 16 bf16 values."""
+    ps, ldp = as_nhwc(probs)
+    if ps.dtype != torch.bfloat16 or ldp < 16 or ldp % 8 or ps.data_ptr() % 16:
+        B, K, H, W = probs.shape
+        buf = torch.zeros((B, H, W, 16), dtype=torch.bfloat16, device=probs.device)
+        buf[..., :K] = probs.detach().permute(0, 2, 3, 1)
+        ps, ldp = buf.permute(0, 3, 1, 2), 16
+    return ps, ldp
+
+
+def ocr_gather_ok(feats, probs):
+    return OCR_KERNELS and feats.is_cuda and feats.dtype == torch.bfloat16 and feats.shape[1] == OCR_GATHER_C and probs.shape[1] <= 16
+
+
+def ocr_attend_ok(q, key):
+    return OCR_KERNELS and q.is_cuda and q.dtype == torch.bfloat16 and q.shape[1] == OCR_ATTEND_C and key.shape[2] <= 16
+
+
+class OcrGatherFn(torch.autograd.Function):
+    """SpatialGather_Module.forward (modeling/UNet3p_res_ocr_SNws.py:21-28): ctx = softmax_pixels(scale * probs) @ feats
+    as two streaming kernels (soft-max statistics, weighted sum) and one for the gradients.  Returns (B, C, K, 1)."""
+
+    @staticmethod
+    def forward(ctx, feats, probs, scale):
+        lib, st = L.lib(), _stream()
+        B, C, H, W = feats.shape
+        K, HW = probs.shape[1], H * W
+        fs, ldf = as_nhwc(feats)
+        if ldf % 8 or fs.data_ptr() % 16:
+            fs, ldf = _pad_channels(fs, ldf, C)
+        ps, ldp = _class_rows(probs)
+        Ts, Tn = lib.snws_ocr_tiles(HW, 0), lib.snws_ocr_tiles(HW, 1)
+        stat = torch.empty((B, Ts, 16, 2), dtype=torch.float32, device=feats.device)
+        L.call("snws_ocr_gather_stats", _ptr(ps), ldp, _ptr(stat), B, HW, K, float(scale), st)
+        part = torch.empty((B, Tn, 16, C), dtype=torch.float32, device=feats.device)
+        _launch("ocr_gather_fwd", 2.0 * B * HW * C, "snws_ocr_gather_fwd", _ptr(fs), ldf, _ptr(ps), ldp, _ptr(stat), _ptr(part),
+                B, HW, C, K, float(scale), st)
+        c32 = torch.empty((B, 16, C), dtype=torch.float32, device=feats.device)
+        L.call("snws_partial_sum_batched", _ptr(part), B, Tn, 16 * C, _ptr(c32), 0, st)
+        ctx.saved = (fs, ldf, ps, ldp, stat, c32, (B, C, H, W), K, float(scale))
+        return _from_rows(c32, K, feats.dtype)
+
+    @staticmethod
+    def backward(ctx, dctx):
+        fs, ldf, ps, ldp, stat, c32, (B, C, H, W), K, scale = ctx.saved
+        ctx.saved = None
+        d16 = _rows16(dctx, K)
+        dot = (c32 * d16.float()).sum(-1).contiguous()
+        dfeats = new_nhwc(B, C, H, W, torch.bfloat16, dctx.device)
+        dprobs = new_nhwc(B, 16, H, W, torch.bfloat16, dctx.device)
+        _launch("ocr_gather_bwd", 4.0 * B * H * W * C, "snws_ocr_gather_bwd", _ptr(fs), ldf, _ptr(ps), ldp, _ptr(stat), _ptr(d16),
+                _ptr(dot), _ptr(dfeats), C, _ptr(dprobs), B, H * W, C, K, scale, _stream())
+        return dfeats, dprobs[:, :K], None
+
+
+class OcrAttendFn(torch.autograd.Function):
+    """The attention of _ObjectAttentionBlock.forward (modeling/UNet3p_res_ocr_SNws.py:87-100) between f_pixel /
+    f_object / f_down and f_up: softmax_classes(scale * query @ key) @ value, one streaming kernel per direction.
+    q (B, Ck, H, W); key, value (B, Ck, K, 1); returns (B, Ck, H, W)."""
+
+    @staticmethod
+    def forward(ctx, q, key, value, scale):
+        B, C, H, W = q.shape
+        K = key.shape[2]
+        qs, ldq = as_nhwc(q)
+        if ldq % 8 or qs.data_ptr() % 16:
+            qs, ldq = _pad_channels(qs, ldq, C)
+        k16, v16 = _rows16(key, K), _rows16(value, K)
+        out = new_nhwc(B, C, H, W, torch.bfloat16, q.device)
+        _launch("ocr_attend_fwd", 4.0 * B * H * W * C, "snws_ocr_attend_fwd", _ptr(qs), ldq, _ptr(k16), _ptr(v16), _ptr(out), C, B,
+                H * W, C, K, float(scale), _stream())
+        ctx.saved = (qs, ldq, k16, v16, (B, C, H, W), K, float(scale), key.dtype, value.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qs, ldq, k16, v16, (B, C, H, W), K, scale, kdt, vdt = ctx.saved
+        ctx.saved = None
+        lib, st, dev = L.lib(), _stream(), dout.device
+        ds, lddo = as_nhwc(dout if dout.dtype == torch.bfloat16 else dout.to(torch.bfloat16))
+        if lddo % 8 or ds.data_ptr() % 16:
+            ds, lddo = _pad_channels(ds, lddo, C)
+        Tn = lib.snws_ocr_tiles(H * W, 2)
+        dq = new_nhwc(B, C, H, W, torch.bfloat16, dev)
+        dkp = torch.empty((B, Tn, 16, C), dtype=torch.float32, device=dev)
+        dvp = torch.empty((B, Tn, 16, C), dtype=torch.float32, device=dev)
+        _launch("ocr_attend_bwd", 6.0 * B * H * W * C, "snws_ocr_attend_bwd", _ptr(qs), ldq, _ptr(ds), lddo, _ptr(k16), _ptr(v16),
+                _ptr(dq), C, _ptr(dkp), _ptr(dvp), B, H * W, C, K, scale, st)
+        dk = torch.empty((B, 16, C), dtype=torch.float32, device=dev)
+        dv = torch.empty((B, 16, C), dtype=torch.float32, device=dev)
+        L.call("snws_partial_sum_batched", _ptr(dkp), B, Tn, 16 * C, _ptr(dk), 0, st)
+        L.call("snws_partial_sum_batched", _ptr(dvp), B, Tn, 16 * C, _ptr(dv), 0, st)
+        return dq, _from_rows(dk, K, kdt), _from_rows(dv, K, vdt), None
+
+
 # ------------------------------------------------------------------------------------------------ conv of an up-sampled map
 class PreparedTaps:
     """The standardized filter of a Conv2dws re-laid as a 1x1 filter with taps*O output channels (tap-major):
