@@ -1028,7 +1028,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1w_kernel(Wgrad1wArgs a) {
 // fragment reads per 10 MFMAs instead of 10 per 9).  The 5/4 split alternates between co-resident workgroups so
 // the four SIMDs stay evenly loaded.  All LDS addresses are a per-lane base plus an immediate, and the fragments
 // of k-step s+1 are read while the MFMAs of step s run (two register sets).
-template <bool FIVE, bool BIAS>
+// M16: v_mfma_f32_16x16x32_bf16 (k-step = one 32-pixel tile row, 4 x 2 output blocks of 16 x 16 per tap) instead of
+// 32x32x16: the same fragment reads and matrix cycles per pixel, but the chip holds a higher clock under this shape.
+template <bool FIVE, bool BIAS, bool M16>
 __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* smem, int bid) {
   using G = WgGeom<64, 9>;
   constexpr int NT = FIVE ? 5 : 4, T0 = FIVE ? 0 : 5;
@@ -1046,21 +1048,33 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   const int ci_half = wave & 1;
   const bool want_bias = BIAS && cit == 0;
 
-  f32x16 acc[NT][2];
+  f32x16 acc[M16 ? 1 : NT][M16 ? 1 : 2];
+  f32x4 acc16[M16 ? NT : 1][M16 ? 4 : 1][M16 ? 2 : 1];    // [tap][out block of 16][in block of 16]
+  if constexpr (M16) {
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+        for (int cbk = 0; cbk < 2; ++cbk) acc16[i][ob][cbk] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+  }
   float* b_lds = reinterpret_cast<float*>(smem + G::DY_BYTES + ((G::X_BYTES + 15) / 16) * 16);   // [4 waves][64 channels]
   if (want_bias) b_lds[tid] = 0.f;   // ordered before its first use by the barrier that follows the first staging
 
   // transposing-read lane geometry (see the generic kernel): lane -> (channel group of 4, pixel within the k-step)
+  // (16x16x32: a 16-lane group reads the SAME 16 channels at the k octet 8 * group of a 32-pixel k-step)
   const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
-  const int rb = (grp & 1) * 16, kb = (grp >> 1) * 8;
-  const int cb0 = kb + gq;   // this lane's first pixel column inside a 16-pixel k-step; the second is cb0 + 4
+  const int rb = M16 ? 0 : (grp & 1) * 16, kb = M16 ? grp * 8 : (grp >> 1) * 8;
+  const int cb0 = kb + gq;   // this lane's first pixel column inside a k-step; the second is cb0 + 4
   // dy tile: pixel p = row*32 + col; its chunk swizzle bit (p >> 1) & 1 only depends on cb0
+  // (16x16x32: abase[h] serves out blocks 2h and, 32 bytes further, 2h + 1)
   const unsigned char* abase[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1179,6 +1193,37 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
       }
     }
 
+    if constexpr (M16) {
+      // k-step = tile row (32 pixels).  Per (k-step, tap, in block) pair one B fragment feeds the four out blocks;
+      // the B fragment of pair f+2 and the A fragments of the next k-step are read while the MFMAs of pair f run.
+      // (in block 1 sits 32 bytes behind block 0: the chunk swizzle only touches chunk bit 2)
+      bf16x8 af[2][4], bq[3];
+      auto load_a = [&](int ks) {
+        const int a_imm = ks * 32 * 128;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+          af[ks & 1][ob] = tr_frag(abase[ob >> 1] + a_imm + (ob & 1) * 32, abase[ob >> 1] + a_imm + (ob & 1) * 32 + 512);
+      };
+      auto load_b = [&](int f) {
+        const int ks = f / (2 * NT), i = (f / 2) % NT, cbk = f & 1;
+        const int b_imm = ks * G::HWd * 128 + cbk * 32;
+        bq[f % 3] = tr_frag(bbase[i][ks & 1] + b_imm, bbase[i][ks & 1] + b_imm + 512);
+      };
+      load_a(0);
+      load_b(0);
+      load_b(1);
+#pragma unroll
+      for (int f = 0; f < 8 * 2 * NT; ++f) {
+        const int ks = f / (2 * NT), i = (f / 2) % NT, cbk = f & 1;
+        if (f % (2 * NT) == 0 && ks + 1 < 8) load_a(ks + 1);
+        if (f + 2 < 8 * 2 * NT) load_b(f + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+          acc16[i][ob][cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks & 1][ob], bq[f % 3], acc16[i][ob][cbk], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     // flat software pipeline over (k-step, tap): the B fragment of pair f+2 and the A fragments of the next k-step
     // are read while the MFMAs of pair f run
     bf16x8 af[2][2], bq[3];
@@ -1205,10 +1250,38 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][1], bq[f % 3], acc[i][1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     __syncthreads();
   }
 
   // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
+  if constexpr (M16) {
+    // D[out channel 16 ob + 4 (lane >> 4) + j][in channel 32 half + 16 cbk + (lane & 15)]
+    if (a.part) {   // partial tile [tap][ob][cbk][j][in-channel half][lane]
+      float* o = a.part + ((int64_t)split * npairs + pair) * 36864 + ci_half * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[((((T0 + i) * 4 + ob) * 2 + cbk) * 4 + j) * 128] = acc16[i][ob][cbk][j];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int co = cot * 64 + ob * 16 + 4 * (lane >> 4) + j;
+              const int ci16 = cit * 64 + ci_half * 32 + cbk * 16 + (lane & 15);
+              if (ci16 < a.Cin && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + (T0 + i)) * a.Cin + ci16, acc16[i][ob][cbk][j]);
+            }
+    }
+  } else {
   const int ci = cit * 64 + ci_half * 32 + (lane & 31);
   const bool ci_ok = ci < a.Cin;
   if (a.part) {   // partial tile [tap][h][r][in-channel half][lane]: which wave holds a tap varies, the slot does not
@@ -1232,6 +1305,7 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
       }
     }
   }
+  }
   if (want_bias && tid < 64) {   // the loop's last barrier ordered every wave's partials
     const float v = b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192];
     if (a.part) a.pbias[((int64_t)split * a.coTiles + cot) * 64 + tid] = v;
@@ -1239,14 +1313,14 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   }
 }
 
-template <bool BIAS>
+template <bool BIAS, bool M16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tg = __builtin_amdgcn_readfirstlane(((wave >> 1) ^ (bid >> 5)) & 1);
-  if (tg == 0) wgrad9_body<true, BIAS>(a, smem, bid);
-  else wgrad9_body<false, BIAS>(a, smem, bid);
+  if (tg == 0) wgrad9_body<true, BIAS, M16>(a, smem, bid);
+  else wgrad9_body<false, BIAS, M16>(a, smem, bid);
 }
 
 // ------------------------------------------------------------------------------------------------- host
@@ -1425,13 +1499,19 @@ int launch_wgrad1w(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
   return SNWS_OK;
 }
 
-template <bool BIAS>
+// SNWS_WGRAD_M16 = 0 selects the 32x32x16 form of the 3x3 wgrad kernel (A/B measurements); default: 16x16x32
+bool wgrad9_m16() {
+  static const bool on = !(getenv("SNWS_WGRAD_M16") && atoi(getenv("SNWS_WGRAD_M16")) == 0);
+  return on;
+}
+
+template <bool BIAS, bool M16>
 int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<64, 9>;
   static PerDeviceOnce once;
   std::atomic<bool>* const attr_set = once.flag();
   if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9_kernel<BIAS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9_kernel<BIAS, M16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1439,7 +1519,7 @@ int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
     }
     if (attr_set) attr_set->store(true, std::memory_order_release);
   }
-  conv_wgrad9_kernel<BIAS><<<grid, 256, G::LDS_BYTES, st>>>(a);
+  conv_wgrad9_kernel<BIAS, M16><<<grid, 256, G::LDS_BYTES, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
   return SNWS_OK;
 }
@@ -1515,7 +1595,7 @@ WgradPlan wgrad_plan(const snws_conv_desc* d, bool det) {
     return p;
   }
   p.npairs = p.coTiles * p.ciTiles;
-  if (c64 && taps == 9 && !generic) { p.kind = 4; p.E = 36864; }
+  if (c64 && taps == 9 && !generic) { p.kind = wgrad9_m16() ? 5 : 4; p.E = 36864; }
   else if (c64 && taps == 1 && !generic) { p.kind = 2; p.E = 4096; }
   else { p.kind = c64 ? 0 : 1; p.E = taps * 4096; }
   // Atomic flush: every workgroup ends with a 64x64x9 float-atomic flush (147 KB; the chip retires ~1.3 TB/s of
@@ -1574,7 +1654,10 @@ int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->C_in; a.Cout = d->C_out; a.ldx = d->ldx; a.lddy = d->ldy;
     a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
     a.coTiles = p.coTiles; a.ciTiles = p.ciTiles; a.tilesPerSplit = p.tilesPerSplit;
-    if (p.kind == 4) rc = dbias ? launch_wgrad9<true>(a, grid, st) : launch_wgrad9<false>(a, grid, st);
+    if (p.kind == 4 || p.kind == 5) {
+      if (p.kind == 5) rc = dbias ? launch_wgrad9<true, true>(a, grid, st) : launch_wgrad9<false, true>(a, grid, st);
+      else rc = dbias ? launch_wgrad9<true, false>(a, grid, st) : launch_wgrad9<false, false>(a, grid, st);
+    }
     else if (p.kind == 2) rc = dbias ? launch_wgrad1<true>(a, grid, st) : launch_wgrad1<false>(a, grid, st);
     else if (p.kind == 0) rc = taps == 9 ? launch_wgrad<64, 9>(a, grid, st) : launch_wgrad<64, 1>(a, grid, st);
     else rc = taps == 9 ? launch_wgrad<16, 9>(a, grid, st) : launch_wgrad<16, 1>(a, grid, st);
