@@ -208,7 +208,7 @@ def main():
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if grouped:   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
+            ops.broadcast(t.data, 0)
     trainer = harness.Trainer(model, lr=0.002, weight_decay=5e-4, total_iters=max(1000, args.steps + args.warmup))
     img, lab = harness.synthetic_batch(args.batch, 14, args.size, 10, device, seed=1 + rank,
                                        dtype=model.compute_dtype)
@@ -234,12 +234,12 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if grouped:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ops.all_reduce(tmax, "max")
     elapsed = float(tmax.item())
     loss_val = float(loss)
     if grouped:
-        lt = loss.clone()
-        dist.all_reduce(lt)
+        lt = loss.detach().clone()
+        ops.all_reduce(lt, "sum")
         loss_val = float(lt)
 
     disk = disk_inference(model, device, rank, world, tiles_per_forward=args.disk_tiles) if args.disk else None

@@ -299,3 +299,24 @@ def test_bench_prints_exactly_one_json_line_on_stdout():
     rf = out["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["launches"] > 0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["traffic"] is None   # traffic: full size only
+
+
+def test_bench_starts_its_own_ranks_for_gpus_2():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns two ranks through
+    torch.distributed.run before touching the GPU and relays rank 0's single JSON line.  On this one-GPU box the two
+    ranks share the card (SNWS_DP_SHARE_GPU=1: gloo, collectives staged through the host) - the same launcher, the
+    same data-parallel code path, the whole-job value = both ranks' images."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SNWS_DP_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--size", "128", "--filters", "32", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and out["value"] > 0
+    assert abs(out["value"] - 4 * 1000.0 / out["ms_per_step"]) < 1e-6 * out["value"]
