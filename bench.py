@@ -131,6 +131,29 @@ def evaluator_throughput(device, reps=24, pairs=6):
             "mIoU": miou}
 
 
+def stream_ceiling(device, reps=10):
+    """What a plain streaming pass reaches on this box: the library's own copy kernel (snws_resample_fwd, mode copy)
+    over a 537 MB bf16 NHWC tensor - 1 read + 1 write, the same shape of traffic as sn_apply.  The SwitchNorm passes
+    are reported against the 8 TB/s data-sheet peak AND against this measured figure."""
+    import ctypes
+    from snws import _lib as L
+    x = torch.randn(16, 512, 512, 64, device=device).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run():
+        L.call("snws_resample_fwd", x.data_ptr(), 64, y.data_ptr(), 64, L.SNWS_BF16, 16, 512, 512, 64, 0, 1, st)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * x.numel() * 2 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def disk_inference(model, device, rank, world, reps=3, tiles_per_forward=12):
     """Full-disk inference: one synthetic (14, 2748, 2748) FY-4A disk resident in HBM -> 36 tiles of 512^2 in eval
     mode, arg-max and stitch on the device, Evaluator against a synthetic label map; tiles are dealt round-robin
@@ -269,12 +292,14 @@ def main():
                         "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc, "launches": cnt,
                         "avg_launch_ms": tt / cnt * 1e3, "flops_per_launch": fl / cnt}
         summary = {}
+        ceiling = stream_ceiling(device)
         for tag, (cnt, work, tt) in sorted(kernels.items()):
             if tag.startswith(("conv", "gemm")):
                 summary[tag] = {"launches": cnt, "ms_per_step": tt / args.steps * 1e3, "TFLOP/s": work / tt / 1e12}
             else:
                 summary[tag] = {"launches": cnt, "ms_per_step": tt / args.steps * 1e3, "GB/s": work / tt / 1e9,
-                                "frac_of_hbm_peak": work / tt / 1e9 / HBM_PEAK_GBS}
+                                "frac_of_hbm_peak": work / tt / 1e9 / HBM_PEAK_GBS,
+                                "frac_of_measured_stream_ceiling": work / tt / 1e9 / ceiling}
         out = {
             "metric": "train images/sec (node) %s 512x512" % cls.__name__, "value": args.batch * world * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -285,6 +310,7 @@ def main():
                                    % (cls.__name__, args.filters, args.size, args.size, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "loss": loss_val, "roofline": roofline, "kernels": summary,
+            "stream_ceiling": {"GB/s": ceiling, "what": "snws_resample_fwd copy, 537 MB bf16 read + write, measured in this run"},
         }
         out["evaluator"] = evaluator_throughput(device)
         if disk is not None:

@@ -105,6 +105,10 @@ int snws_conv_mfma_tiles(int H, int W);
 int snws_conv_mfma_fwd(const snws_conv_desc* d, const void* x, const void* pack_fwd, const float* bias, void* y,
                        float* stat_part, void* stream);
 int snws_conv_mfma_dgrad(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx, void* stream);
+/* dx += dgrad (same operands as snws_conv_mfma_dgrad): for an input tensor with several consumers, every consumer
+ * after the first adds its share of the gradient in place instead of writing a tensor that a separate add kernel
+ * would have to fold in (autograd's accumulation of modeling/UNet3p_SNws.py:127-156's shared skips). */
+int snws_conv_mfma_dgrad_acc(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx, void* stream);
 /* dgrad whose epilogue also runs pass 1 of the SwitchNorm backward (what snws_sn_bwd_reduce computes) for the
  * SwitchNorm(+ReLU) layers that produced this convolution's input: the gradient this launch writes, dx, IS their
  * incoming gradient when the convolution is their only consumer (autograd of modeling/snorm.py:41-81 chained to
@@ -335,6 +339,10 @@ int snws_resample_fwd(const void* src, int64_t lds, void* dst, int64_t ldd, int 
                       int mode, int k, void* stream);
 int snws_resample_bwd(const void* ddst, int64_t ldd, const void* src, int64_t lds, void* dsrc, int64_t ldds,
                       int dtype, int N, int H, int W, int C, int mode, int k, int accumulate, void* stream);
+/* dst += src over NHWC tensors of `pixels` pixels x C channels (f32 or bf16, f32 accumulation): the in-place sum of
+ * a gradient with several contributors, for contributors whose own kernels cannot add on the fly (no counterpart in
+ * the reference: autograd's implicit accumulation). */
+int snws_add_inplace(void* dst, int64_t ldd, const void* src, int64_t lds, int dtype, int64_t pixels, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution of a bilinearly up-sampled map without materialising it - replaces the pairs

@@ -73,6 +73,7 @@ struct FwdArgs {
   int N, H, W, Cout;
   int64_t ldx, ldy;
   int tilesX, tilesY, coTiles, nchunks;
+  int accumulate;     // != 0: y += result (a gradient with several contributors: a later contributor adds in place)
 };
 // arguments of the dgrad variant whose epilogue also reduces for the SwitchNorm layers behind its output
 struct FwdArgsBwr : FwdArgs {
@@ -522,7 +523,21 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
   }
   // ---- the output tile, last: nothing in this workgroup waits for these stores
   if (lane_ok) {
-    if (rows == FWD_TH) {
+    if (a.accumulate) {     // kernel-uniform: add to what the destination holds (f32 sum of the two bf16 values, rounded once)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < rows) {
+          const uint4 nv = *reinterpret_cast<const uint4*>(lp + i * 32 * OUT_STRIDE);
+          const uint4 ov = *reinterpret_cast<const uint4*>(yp + i * ystep);
+          const unsigned n4[4] = {nv.x, nv.y, nv.z, nv.w}, o4[4] = {ov.x, ov.y, ov.z, ov.w};
+          unsigned r4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            r4[e] = pack_bf16x2(__uint_as_float(n4[e] << 16) + __uint_as_float(o4[e] << 16),
+                                __uint_as_float(n4[e] & 0xffff0000u) + __uint_as_float(o4[e] & 0xffff0000u));
+          *reinterpret_cast<uint4*>(yp + i * ystep) = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+        }
+    } else if (rows == FWD_TH) {
 #pragma unroll
       for (int i = 0; i < 16; ++i)
         *reinterpret_cast<uint4*>(yp + i * ystep) = *reinterpret_cast<const uint4*>(lp + i * 32 * OUT_STRIDE);
@@ -1396,7 +1411,7 @@ int launch_fwd_any(const std::conditional_t<BWR, FwdArgsBwr, FwdArgs>& a, int kc
 // runs y(C_out_run channels) = conv(x(C_in_run channels), pack)
 int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_run, int taps, const void* x, int64_t ldx,
                  const void* pack, const float* bias, void* y, int64_t ldy, float* stat, hipStream_t st,
-                 const snws_sn_bwd_seg* segs = nullptr, int n_segs = 0) {
+                 const snws_sn_bwd_seg* segs = nullptr, int n_segs = 0, int accumulate = 0) {
   SNWS_CHECK_ARG(x && pack && y, "%s: NULL pointer", fn);
   SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)pack & 15) == 0,
                  "%s: pointers must be 16-byte aligned", fn);
@@ -1405,6 +1420,7 @@ int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_ru
   a.x = (const bf16_t*)x; a.pack = (const bf16_t*)pack; a.bias = bias; a.y = (bf16_t*)y; a.stat = stat;
   a.N = N; a.H = H; a.W = W; a.Cout = c_out_run; a.ldx = ldx; a.ldy = ldy;
   a.tilesX = cdiv(W, FWD_TW); a.tilesY = cdiv(H, FWD_TH); a.coTiles = g.c_out_p / 64; a.nchunks = g.nchunks;
+  a.accumulate = accumulate;
   bool bwr = false;
   if (n_segs > 0) {
     if (a.coTiles > MAX_BWR_TILES) SNWS_UNSUPPORTED("%s: more than %d output-channel tiles", fn, MAX_BWR_TILES * 64);
@@ -1541,6 +1557,14 @@ extern "C" int snws_conv_mfma_dgrad(const snws_conv_desc* d, const void* dy, con
   if (d->C_out % 16 || d->C_in % 8) SNWS_UNSUPPORTED("snws_conv_mfma_dgrad: C_out %d must be a multiple of 16 and C_in %d of 8", d->C_out, d->C_in);
   return run_fwd_like("snws_conv_mfma_dgrad", d->N, d->H, d->W, d->C_out, d->C_in, d->kh * d->kw, dy, d->ldy, pack_dgrad,
                       nullptr, dx, d->ldx, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int snws_conv_mfma_dgrad_acc(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx,
+                                        void* stream) {
+  if (int rc = check_mfma_desc(d, "snws_conv_mfma_dgrad_acc")) return rc;
+  if (d->C_out % 16 || d->C_in % 8) SNWS_UNSUPPORTED("snws_conv_mfma_dgrad_acc: C_out %d must be a multiple of 16 and C_in %d of 8", d->C_out, d->C_in);
+  return run_fwd_like("snws_conv_mfma_dgrad_acc", d->N, d->H, d->W, d->C_out, d->C_in, d->kh * d->kw, dy, d->ldy, pack_dgrad,
+                      nullptr, dx, d->ldx, nullptr, (hipStream_t)stream, nullptr, 0, 1);
 }
 
 extern "C" int snws_conv_mfma_dgrad_sn(const snws_conv_desc* d, const void* dy, const void* pack_dgrad, void* dx,

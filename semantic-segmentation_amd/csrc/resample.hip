@@ -273,3 +273,49 @@ extern "C" int snws_resample_bwd(const void* ddst, int64_t ldd, const void* src,
     return run_bwd<bf16_t, 8>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, accumulate, st);
   return run_bwd<bf16_t, 1>(ddst, ldd, src, lds_, dsrc, ldds, N, H, W, C, mode, k, accumulate, st);
 }
+
+
+// dst += src over an NHWC tensor (pixel strides may differ): the in-place sum of a gradient that several consumers
+// contribute to, for contributors whose kernels cannot add on the fly.  f32 accumulation, one rounding.
+namespace {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, int64_t ldd, const T* __restrict__ src, int64_t lds,
+                                                          int64_t pixels, int C) {
+  const int cg = C / V;
+  const int64_t total = pixels * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t px = i / cg;
+    const int c = (int)(i - px * cg) * V;
+    float a[V], b[V];
+    Vec<T, V>::load(dst + px * ldd + c, a);
+    Vec<T, V>::load(src + px * lds + c, b);
+#pragma unroll
+    for (int v = 0; v < V; ++v) a[v] += b[v];
+    Vec<T, V>::store(dst + px * ldd + c, a);
+  }
+}
+}  // namespace
+
+extern "C" int snws_add_inplace(void* dst, int64_t ldd, const void* src, int64_t lds, int dtype, int64_t pixels, int C,
+                                void* stream) {
+  SNWS_CHECK_ARG(dst && src && pixels >= 0 && C >= 1 && ldd >= C && lds >= C, "snws_add_inplace: bad arguments");
+  SNWS_CHECK_ARG(dtype == SNWS_F32 || dtype == SNWS_BF16, "snws_add_inplace: dtype %d is not F32/BF16", dtype);
+  if (pixels == 0) return SNWS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool a16 = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+  if (dtype == SNWS_BF16) {
+    const bool vec = a16 && C % 8 == 0 && ldd % 8 == 0 && lds % 8 == 0;
+    const int64_t items = pixels * (vec ? C / 8 : C);
+    const unsigned grid = (unsigned)(cdiv64(items, 256) < 65536 * 4 ? cdiv64(items, 256) : 65536 * 4);
+    if (vec) add_inplace_kernel<bf16_t, 8><<<grid, 256, 0, st>>>((bf16_t*)dst, ldd, (const bf16_t*)src, lds, pixels, C);
+    else add_inplace_kernel<bf16_t, 1><<<grid, 256, 0, st>>>((bf16_t*)dst, ldd, (const bf16_t*)src, lds, pixels, C);
+  } else {
+    const bool vec = a16 && C % 4 == 0 && ldd % 4 == 0 && lds % 4 == 0;
+    const int64_t items = pixels * (vec ? C / 4 : C);
+    const unsigned grid = (unsigned)(cdiv64(items, 256) < 65536 * 4 ? cdiv64(items, 256) : 65536 * 4);
+    if (vec) add_inplace_kernel<float, 4><<<grid, 256, 0, st>>>((float*)dst, ldd, (const float*)src, lds, pixels, C);
+    else add_inplace_kernel<float, 1><<<grid, 256, 0, st>>>((float*)dst, ldd, (const float*)src, lds, pixels, C);
+  }
+  SNWS_LAUNCH_CHECK("snws_add_inplace");
+  return SNWS_OK;
+}

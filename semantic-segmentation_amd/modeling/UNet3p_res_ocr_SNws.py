@@ -184,7 +184,8 @@ class UNet3p_res_ocr_SNws(nn.Module):
             if lvl > 1:
                 t = pools.get(lvl - 1, 2)       # shared with the decoder's factor-2 skip of the same map
             t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
-            enc[lvl] = t
+            # encoder maps 1..4 feed the next stage's pool AND the decoder's skips: one shared gradient tensor
+            enc[lvl] = t = ops.share_grad(t) if lvl < 5 else t
         convu1 = full_scale_decoder(self, enc, pools)
         out_aux = self.aux_head(convu1)
         feats = self.conv3x3_ocr(convu1)

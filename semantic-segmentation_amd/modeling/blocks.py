@@ -208,7 +208,8 @@ class PoolPyramid:
             return self.enc[src]
         key = (src, k)
         if key not in self.maps:
-            self.maps[key] = ops.max_pool_ceil(self.get(src, k // 2), 2)
+            # (several consumers: the next pool, a decoder skip block, an encoder stage - their gradients meet in one tensor)
+            self.maps[key] = ops.share_grad(ops.max_pool_ceil(self.get(src, k // 2), 2))
         return self.maps[key]
 
 
@@ -221,7 +222,7 @@ def full_scale_decoder(m, enc, pools=None, head=None):
     enc_cat = {1: m.convd1_cat, 2: m.convd2_cat, 3: m.convd3_cat, 4: m.convd4_cat}
     if pools is None:
         pools = PoolPyramid(enc)
-    z5 = m.conv5_cat.taps(enc[5])
+    z5 = ops.share_grad(m.conv5_cat.taps(enc[5]))      # one tap map, consumed by every decoder scale
     zdec = {}
     dec = {}
     f = m.Cat_channels
@@ -241,7 +242,7 @@ def full_scale_decoder(m, enc, pools=None, head=None):
                     parts.append(enc_cat[src](enc[src], out=out))
                 else:                   # decoder map of a coarser level, up-sampled
                     if src not in zdec:
-                        zdec[src] = m.convu_cat.taps(dec[src])
+                        zdec[src] = ops.share_grad(m.convu_cat.taps(dec[src]))
                     parts.append(m.convu_cat.up(zdec[src], 2 ** (src - level), out=out))
             # concat order: encoder sources fine->coarse, then decoder sources fine->coarse, then the centre
             parts.append(m.conv5_cat.up(z5, 2 ** (5 - level), out=buf[:, 4 * f:5 * f]))

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "snws_sn_noalloc_floats": (c_int64, [c_int, c_int64, c_int]),
     "snws_sn_apply_noalloc": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, P, P, P, c_int, c_int64, c_int,
                                       c_float, c_float, c_int, c_int, c_int, c_int, P]),
+    "snws_conv_mfma_dgrad_acc": (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    "snws_add_inplace": (c_int, [P, c_int64, P, c_int64, c_int, c_int64, c_int, P]),
     "snws_gemm1x1_supported": (c_int, [c_int, c_int]),
     "snws_gemm1x1": (c_int, [P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int, P]),
     "snws_ocr_tiles": (c_int, [c_int64, c_int]),

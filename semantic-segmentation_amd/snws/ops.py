@@ -398,7 +398,80 @@ def fused_bwd_partials(s, dys, lddy):
     return part, T
 
 
-def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=None, in_segs=None):
+# Gradient sharing for tensors with several consumers (the encoder maps, their pooled copies and the tap maps of
+# the UNet3+ full-scale skips, modeling/UNet3p_SNws.py:127-156).  Autograd would sum the consumers' gradients with
+# one out-of-place add per extra consumer.  share_grad(x) instead hands the consumers a tensor that carries a
+# GradSlot: the first consumer to run backward returns its gradient tensor as usual and parks it in the slot; every
+# later consumer adds its share INTO that tensor - in its own kernel's epilogue where the kernel can
+# (snws_conv_mfma_dgrad_acc, snws_resample_bwd with accumulate), else with snws_add_inplace - and returns None.  The
+# engine runs the producer's backward only after all consumers have reported, so it sees the finished sum.  Every
+# consumer of a shared tensor must be one of the slot-aware ops below: the identity node share_grad inserts checks that
+# the gradient arriving at the producer IS the parked tensor and raises otherwise.  A shared tensor carries no
+# SwitchNorm tags: a consumer's fused dgrad epilogue would reduce one share of the gradient, not the sum.
+GRAD_SHARE = os.environ.get("SNWS_GRAD_SHARE", "1") != "0"
+
+
+class GradSlot:
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class _GradJoinFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.slot.buf = ctx.slot.buf, None
+        if buf is not None and (g.data_ptr() != buf.data_ptr() or g.shape != buf.shape or g.dtype != buf.dtype):
+            raise RuntimeError("share_grad: a consumer that does not know about shared gradients contributed to this tensor "
+                               "(the gradient that arrived is not the one the slot-aware consumers accumulated into)")
+        return g, None
+
+
+def share_grad(x):
+    """Mark x - about to be consumed by several libsnws ops - for in-place gradient accumulation (see above)."""
+    if not (GRAD_SHARE and torch.is_grad_enabled() and x.requires_grad):
+        return x
+    slot = GradSlot()
+    y = _GradJoinFn.apply(x, slot)
+    y._snws_gslot = slot
+    return y
+
+
+def grad_slot(x):
+    return getattr(x, "_snws_gslot", None)
+
+
+def add_inplace(dst, src):
+    """dst += src for logical (N, C, H, W) tensors with NHWC storage."""
+    d, ldd = as_nhwc(dst)
+    if d.data_ptr() != dst.data_ptr():
+        raise RuntimeError("add_inplace: the destination is not NHWC storage")
+    if src.dtype != dst.dtype:
+        src = src.to(dst.dtype)
+    s_, lds = as_nhwc(src)
+    N, C, H, W = dst.shape
+    _launch("grad_add", 3.0 * dst.element_size() * N * C * H * W, "snws_add_inplace", _ptr(d), ldd, _ptr(s_), lds, dtype_code(d),
+            N * H * W, C, _stream())
+
+
+def deliver_grad(slot, dx):
+    """What a slot-aware consumer returns for its input gradient dx."""
+    if slot is None or dx is None:
+        return dx
+    if slot.buf is None:
+        slot.buf = dx
+        return dx
+    add_inplace(slot.buf, dx)
+    return None
+
+
+def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=None, in_segs=None, gslot=None):
     """Returns (dx or None, dw (O,I/g,kh,kw) f32 or None, dbias f32 or None).  bias_key: grad_key(bias), which routes
     the bias gradient to its slot in a flat gradient buffer (the weight's is found through `weight`).  in_segs: the
     SwitchNorm tags of the convolution's input (input_segments)."""
@@ -417,19 +490,33 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=N
     elif need_dx:
         done = False
         if used_mfma is True and cfg.O % 16 == 0 and lddy % 8 == 0 and dys.data_ptr() % 16 == 0:
-            dxp = new_nhwc(N, c_run, H, W, dys.dtype, dev)
-            d = cfg.desc(N, H, W, c_run, c_run, lddy)
-            try:
-                flops = 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw
-                _launch_dgrad(cfg, d, dys, prep, dxp, in_segs, N, H, W, flops)
-                dx = dxp[:, :C] if c_run != C else dxp
-                done = True
-            except L.SnwsUnsupported:
-                pass
+            flops = 2.0 * N * H * W * cfg.O * cfg.I * cfg.kh * cfg.kw
+            acc = gslot.buf if gslot is not None else None
+            if acc is not None and c_run == C and acc.dtype == dys.dtype and tuple(acc.shape) == (N, C, H, W):
+                # a later contributor to a shared gradient: the dgrad epilogue adds into the parked tensor
+                a_, lda = as_nhwc(acc)
+                if a_.data_ptr() == acc.data_ptr() and lda % 8 == 0 and a_.data_ptr() % 16 == 0:
+                    d = cfg.desc(N, H, W, c_run, lda, lddy)
+                    try:
+                        _launch("conv_mfma_dgrad_k%d_kc%d" % (cfg.kh, 32 if cfg.O % 32 == 0 else 16), flops,
+                                "snws_conv_mfma_dgrad_acc", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(a_), _stream())
+                        done, gslot = True, None          # delivered: nothing to return
+                    except L.SnwsUnsupported:
+                        pass
+            if not done:
+                dxp = new_nhwc(N, c_run, H, W, dys.dtype, dev)
+                d = cfg.desc(N, H, W, c_run, c_run, lddy)
+                try:
+                    _launch_dgrad(cfg, d, dys, prep, dxp, in_segs, N, H, W, flops)
+                    dx = dxp[:, :C] if c_run != C else dxp
+                    done = True
+                except L.SnwsUnsupported:
+                    pass
         if not done:
             dx = new_nhwc(N, C, H, W, dys.dtype, dev)
             d = cfg.desc(N, H, W, C, C, lddy)
             L.call("snws_conv_direct_dgrad", ctypes.byref(d), dt, _ptr(dys), _ptr(prep.ohwi), _ptr(dx), _stream())
+    dx = deliver_grad(gslot, dx)
     if need_dw or need_db:
         dw, db = _conv_backward_weights(dys, lddy, prep, saved, weight, need_dw, need_db, bias_key)
     return dx, dw, db
@@ -925,7 +1012,7 @@ class Conv2dwsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, prep, force_direct):
         y, _, saved = conv_forward(x, prep, bias, want_stats=False, force_direct=force_direct)
-        ctx.in_segs = input_segments(x)
+        ctx.in_segs, ctx.gslot = input_segments(x), grad_slot(x)
         ctx.prep, ctx.saved, ctx.has_bias, ctx.bias_key = prep, saved, bias is not None, grad_key(bias)
         ctx.save_for_backward(weight)
         return y
@@ -934,8 +1021,8 @@ class Conv2dwsFn(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
-        ctx.in_segs = None
+        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        ctx.in_segs = ctx.gslot = None
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db, None, None
@@ -1059,7 +1146,7 @@ class ConvSnReluFn(torch.autograd.Function):
                                                                        device=x.device)
         y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift, out=out)
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
-        ctx.bias_key, ctx.in_segs = grad_key(bias), input_segments(x)
+        ctx.bias_key, ctx.in_segs, ctx.gslot = grad_key(bias), input_segments(x), grad_slot(x)
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.save_for_backward(weight)
         return y
@@ -1070,8 +1157,8 @@ class ConvSnReluFn(torch.autograd.Function):
         dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn)
         ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
-        ctx.in_segs = None
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        ctx.in_segs = ctx.gslot = None
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
@@ -1115,7 +1202,7 @@ class ConvSnReluHeadFn(torch.autograd.Function):
         _launch("sn_apply_head", 2.0 * N * H * W * (C + 16), "snws_sn_apply_head", _ptr(sn["xs"]), sn["ldx"], _ptr(sn["ctx"]),
                 _ptr(sn["beta"]), _ptr(hw16), _ptr(hb16), _ptr(logits), N, H * W, C, 1, _stream())
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn, bias is not None
-        ctx.bias_key, ctx.in_segs = grad_key(bias), input_segments(x)
+        ctx.bias_key, ctx.in_segs, ctx.gslot = grad_key(bias), input_segments(x), grad_slot(x)
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.hw16, ctx.ncls, ctx.head_keys = hw16, ncls, (grad_key(head_w), grad_key(head_b))
         ctx.head_shape, ctx.has_head_bias = tuple(head_w.shape), head_b is not None
@@ -1161,8 +1248,8 @@ class ConvSnReluHeadFn(torch.autograd.Function):
         dconv, dg, dbeta, dmw, dvw = sn_backward_pass2(s, p1, apply_fn=apply_fn)
         ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
-        ctx.in_segs = None
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        ctx.in_segs = ctx.gslot = None
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
@@ -1183,7 +1270,7 @@ class ConvSnAddReluFn(torch.autograd.Function):
                                                                        device=x.device)
         y, sn_saved = sn_forward(conv_out, p, True, stat_part=stat, stat_shift=shift, residual=residual)
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
-        ctx.bias_key, ctx.in_segs = grad_key(bias), input_segments(x)
+        ctx.bias_key, ctx.in_segs, ctx.gslot = grad_key(bias), input_segments(x), grad_slot(x)
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.res_dtype = residual.dtype
         ctx.save_for_backward(weight)
@@ -1200,8 +1287,8 @@ class ConvSnAddReluFn(torch.autograd.Function):
             dres = torch.where(y > 0, dy.to(y.dtype), torch.zeros((), dtype=y.dtype, device=y.device)).to(ctx.res_dtype)
         ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
-        ctx.in_segs = None
+        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        ctx.in_segs = ctx.gslot = None
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
@@ -1354,7 +1441,7 @@ class TapConvFn(torch.autograd.Function):
             saved = (xs, ldx, tuple(x.shape), True)
         else:
             z, _, saved = conv_forward(x, taps_prep.prep, None)
-        ctx.tp, ctx.saved, ctx.in_segs = taps_prep, saved, input_segments(x)
+        ctx.tp, ctx.saved, ctx.in_segs, ctx.gslot = taps_prep, saved, input_segments(x), grad_slot(x)
         ctx.save_for_backward(weight)
         return z
 
@@ -1364,8 +1451,8 @@ class TapConvFn(torch.autograd.Function):
         tp = ctx.tp
         cfg = tp.cfg
         dx, dwre, _ = conv_backward(dz, tp.prep, ctx.saved, None, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                    False, None, ctx.in_segs)
-        ctx.in_segs = None
+                                    False, None, ctx.in_segs, ctx.gslot)
+        ctx.in_segs = ctx.gslot = None
         dw = None
         if dwre is not None:
             g = dwre.view(cfg.kh, cfg.kw, cfg.O, cfg.Ig).permute(2, 0, 1, 3).contiguous()
@@ -1387,6 +1474,7 @@ class UpTapSnReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, bias, gamma, beta, mean_weight, var_weight, p, k, ksize, c_out, relu, out=None):
         require_gpu(z, "ConvSnRelu")
+        ctx.gslot = grad_slot(z)
         N, CZ, h, w = z.shape
         zs, ldz = as_nhwc(z)
         conv_out = new_nhwc(N, c_out, h * k, w * k, z.dtype, z.device)
@@ -1422,6 +1510,7 @@ class UpTapSnReluFn(torch.autograd.Function):
         _launch("upconv_bwd", work, "snws_upconv_bwd", _ptr(dconv), c_out, _ptr(dz), CZ, dtype_code(dconv), N, h, w,
                 c_out, k, ksize, _stream())
         db = dxsum if ctx.has_bias else None
+        dz, ctx.gslot = deliver_grad(ctx.gslot, dz), None
         return dz, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, None, None, None, None, None, None
 
 
@@ -1551,6 +1640,7 @@ class ResampleFn(torch.autograd.Function):
         _launch("resample_fwd", float(x.element_size()) * N * C * (H * W + OH * OW), "snws_resample_fwd", _ptr(xs), ld,
                 _ptr(y), C, dtype_code(x), N, H, W, C, m, k, _stream())
         ctx.meta = (m, k, (N, C, H, W), ld)
+        ctx.gslot = grad_slot(x)
         ctx.save_for_backward(xs if m == 1 else None)
         return y
 
@@ -1559,11 +1649,20 @@ class ResampleFn(torch.autograd.Function):
         m, k, (N, C, H, W), ld = ctx.meta
         (xs,) = ctx.saved_tensors
         dys, ldd = as_nhwc(dy)
-        dx = new_nhwc(N, C, H, W, dys.dtype, dys.device)      # written in full by the kernel (accumulate = 0)
         OH, OW = dy.shape[2], dy.shape[3]
+        slot, ctx.gslot = ctx.gslot, None
+        acc = slot.buf if slot is not None else None
+        if acc is not None and acc.dtype == dys.dtype and tuple(acc.shape) == (N, C, H, W):
+            a_, lda = as_nhwc(acc)
+            if a_.data_ptr() == acc.data_ptr():
+                # a later contributor to a shared gradient: the kernel adds into the parked tensor (accumulate = 1)
+                _launch("resample_bwd", float(dys.element_size()) * N * C * (2 * H * W + OH * OW), "snws_resample_bwd", _ptr(dys),
+                        ldd, _ptr(xs), ld, _ptr(a_), lda, dtype_code(dys), N, H, W, C, m, k, 1, _stream())
+                return None, None, None
+        dx = new_nhwc(N, C, H, W, dys.dtype, dys.device)      # written in full by the kernel (accumulate = 0)
         _launch("resample_bwd", float(dys.element_size()) * N * C * (H * W + OH * OW), "snws_resample_bwd", _ptr(dys),
                 ldd, _ptr(xs), ld, _ptr(dx), C, dtype_code(dys), N, H, W, C, m, k, 0, _stream())
-        return dx, None, None
+        return deliver_grad(slot, dx), None, None
 
 
 def max_pool_ceil(x, k):
