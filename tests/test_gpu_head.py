@@ -194,3 +194,61 @@ def test_head_entry_points_reject_unsupported_shapes():
     # backward partial rows per image: 2048-pixel runs, x4 pixel groups at C = 64
     assert lib.snws_sn_head_tiles(2048, 320, 1) == 1 and lib.snws_sn_head_tiles(2049, 320, 1) == 2
     assert lib.snws_sn_head_tiles(2048, 64, 1) == 4 and lib.snws_sn_head_tiles(2049, 320, 0) == 2
+
+
+# ================================================================== shared gradients of multi-consumer tensors
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
+def test_shared_gradient_slots_match_autograd_accumulation(dtype, tol):
+    """A tensor consumed by two fused conv blocks, a max-pool and a tap convolution + two up-sampled consumers of its
+    tap map: with ops.share_grad the consumers add their gradients in place (dgrad epilogue, pooling backward,
+    snws_add_inplace); the input gradient and every parameter gradient must equal what autograd's own accumulation
+    gives (float32: to rounding of the summation order; bf16: one bf16 rounding per partial sum differs)."""
+    from modeling.blocks import ConvSnRelu
+    from snws import ops
+    torch.manual_seed(21)
+    N, C, H, W = 2, 64, 32, 32
+    prod = ConvSnRelu(C, C).to(DEV).train()
+    c1, c2, ct = ConvSnRelu(C, C).to(DEV).train(), ConvSnRelu(C, 2 * C).to(DEV).train(), ConvSnRelu(C, C).to(DEV).train()
+    mods = [prod, c1, c2, ct]
+    x = torch.randn(N, C, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = [torch.randn(N, C, H, W, device=DEV), torch.randn(N, 2 * C, H, W, device=DEV), torch.randn(N, C, H // 2, W // 2, device=DEV),
+         torch.randn(N, C, 2 * H, 2 * W, device=DEV), torch.randn(N, C, 4 * H, 4 * W, device=DEV)]
+    res = {}
+    saved = ops.GRAD_SHARE
+    try:
+        for share in (True, False):
+            ops.GRAD_SHARE = share
+            for m in mods:
+                m.zero_grad(set_to_none=True)
+            xg = x.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+            ops.PROFILE = []
+            t = ops.share_grad(prod(xg))
+            assert (ops.grad_slot(t) is not None) == share
+            z = ops.share_grad(ct.taps(t))
+            outs = [c1(t), c2(t), ops.max_pool_ceil(t, 2), ct.up(z, 2), ct.up(z, 4)]
+            loss = sum((o.float() * gi).sum() for o, gi in zip(outs, g))
+            loss.backward()
+            tags = [r[0] for r in ops.PROFILE]
+            ops.PROFILE = None
+            assert ("grad_add" in tags) == share          # the second consumer of the tap map adds with snws_add_inplace
+            res[share] = [xg.grad.float().clone()] + [p.grad.float().clone() for m in mods for p in m.parameters()]
+    finally:
+        ops.GRAD_SHARE = saved
+        ops.PROFILE = None
+    for a, b in zip(res[True], res[False]):
+        assert l2err(a, b) < tol, (a.shape, l2err(a, b))
+
+
+def test_shared_gradient_guard_catches_an_unaware_consumer():
+    """A consumer that does not know about shared gradients (here: a plain torch op) makes autograd sum out of place;
+    the identity node of share_grad notices that the gradient it receives is not the parked tensor and raises instead
+    of silently losing a contribution."""
+    from modeling.blocks import ConvSnRelu
+    from snws import ops
+    torch.manual_seed(2)
+    blk, c1 = ConvSnRelu(64, 64).to(DEV).train(), ConvSnRelu(64, 64).to(DEV).train()
+    x = torch.randn(1, 64, 16, 16, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    t = ops.share_grad(blk(x))
+    loss = c1(t).float().sum() + (t.float() * 2).sum()
+    with pytest.raises(RuntimeError, match="share_grad"):
+        loss.backward()
