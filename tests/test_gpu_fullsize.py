@@ -440,3 +440,104 @@ def test_predict_disk_full_fy4a_disk_matches_tile_by_tile():
     ev = Evaluator(10)
     ev.add_batch(gt.to(DEV), got[None])
     assert np.array_equal(ev._matrix(), O.confusion_matrix(gt.numpy(), got[None].cpu().numpy(), 10).astype(np.float64))
+
+
+# ================================================================== round-2 kernels at the benchmark's sizes
+@pytest.mark.parametrize("N_out,K", [(512, 1024), (576, 320)])
+def test_gemm1x1_full_size_exact_checksums(N_out, K):
+    """snws_gemm1x1 over all 16 x 512 x 512 pixels (OCR head's 1024 -> 512 layer; the 320 -> 576 tap convolution at
+    its largest resolution) on sparse small-integer operands: every product and partial sum is exact, so each
+    output is an integer below 256 stored exactly in bf16, and pixel-weighted / channel-weighted checksums of the
+    output must EQUAL the checksums computed from the inputs by the associativity of the product."""
+    import ctypes
+    from snws import _lib as L
+    torch.manual_seed(K)
+    M = 16 * 512 * 512 if N_out == 512 else 16 * 256 * 256
+    x = (torch.randint(-2, 3, (M, K), device=DEV, dtype=torch.int8) * (torch.rand(M, K, device=DEV) < 0.02)).to(torch.bfloat16)
+    w = (torch.randint(-2, 3, (N_out, K), device=DEV) * (torch.rand(N_out, K, device=DEV) < 0.05)).to(torch.bfloat16)
+    b = torch.randint(-3, 4, (N_out,), device=DEV).float()
+    y = torch.empty(M, N_out, device=DEV, dtype=torch.bfloat16)
+    L.call("snws_gemm1x1", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N_out, M, N_out, K,
+           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    q = ((torch.arange(M, device=DEV) * 7 + 3) % 5 - 2).double()          # pixel weights
+    r = ((torch.arange(N_out, device=DEV) * 3 + 1) % 7 - 3).double()      # channel weights
+    yd = y.double()
+    assert float(yd.abs().max()) < 256
+    # sum_m q[m] y[m][n] = sum_k (sum_m q[m] x[m][k]) w[n][k] + b[n] sum q
+    lhs = q @ yd
+    rhs = (q @ x.double()) @ w.double().t() + b.double() * q.sum()
+    assert torch.equal(lhs, rhs)
+    # sum_n r[n] y[m][n] = x[m] . (sum_n r[n] w[n]) + r . b
+    lhs2 = yd @ r
+    rhs2 = x.double() @ (r @ w.double()) + float(r @ b.double())
+    assert torch.equal(lhs2, rhs2)
+
+
+def test_fused_head_full_size_matches_unfused():
+    """The fused last block + head at the benchmark's size (16 x 320 x 512 x 512, 10 classes) against the unfused
+    path of the same library: logits, the input gradient and the head's gradients (relative L2 1e-2); and the fused
+    op twice gives bit-identical results (its head gradients are fixed-order sums of 2048 per-wave partials)."""
+    from modeling.blocks import ConvSnRelu, finish_logits, head_conv
+    torch.manual_seed(4)
+    blk = ConvSnRelu(320, 320).to(DEV).train()
+    head = torch.nn.Conv2d(320, 10, 1).to(DEV)
+    x = torch.randn(16, 512, 512, 320, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+    dl = (torch.randn(16, 512, 512, 10, device=DEV) * 1e-3).permute(0, 3, 1, 2)
+
+    def run(fused):
+        for m in (blk, head):
+            m.zero_grad(set_to_none=True)
+        xg = x.detach().requires_grad_(True)
+        lg = finish_logits(blk.with_head(xg, head), 10) if fused else head_conv(head, blk(xg))
+        lg.backward(dl)
+        return [lg.detach(), xg.grad, head.weight.grad.clone(), head.bias.grad.clone(), blk[0].weight.grad.clone(),
+                blk[1].weight.grad.clone()]
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    a, a2, b = run(True), run(True), run(False)
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)
+    for u, v in zip(a, b):
+        assert rel(u, v) < 1e-2, rel(u, v)
+
+
+def test_ocr_attention_full_size_properties():
+    """OCR attention at the benchmark's size (16 x 512 x 512 pixels): with identical keys the soft-max over the K
+    classes is uniform whatever the query, so every output pixel must be the mean of the K value rows (to bf16
+    rounding of the 1/K probabilities); with one key far ahead of the others the output is that class's value row.
+    The gather with constant class scores must return the mean feature vector of each image."""
+    from snws import ops
+    torch.manual_seed(9)
+    B, H, W, K = 16, 512, 512, 10
+    C = ops.OCR_ATTEND_C
+    q = torch.randn(B, H, W, C, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+    key_row = torch.randn(B, 1, 1, C, device=DEV).to(torch.bfloat16)
+    key = key_row.expand(B, K, 1, C).contiguous().permute(0, 3, 1, 2)
+    val = torch.randn(B, K, 1, C, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        out = ops.OcrAttendFn.apply(q, key, val, C ** -0.5)
+    p = torch.tensor(1.0 / K).to(torch.bfloat16).float()        # the probability as the kernel rounds it
+    want = (val.float().permute(0, 2, 3, 1).reshape(B, K, C) * p).sum(1)            # (B, C)
+    got = out.float().permute(0, 2, 3, 1).reshape(B, H * W, C)
+    assert float((got - want[:, None, :]).abs().max()) < 2e-2 * float(want.abs().max())
+    assert float((got.mean(1) - want).abs().max()) < 1e-2 * float(want.abs().max())
+    # a dominant key: q . key_0 = +large, the others 0
+    q1 = torch.ones(B, H, W, C, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+    key1 = torch.zeros(B, K, 1, C, device=DEV, dtype=torch.bfloat16)
+    key1[:, 3] = 8.0
+    with torch.no_grad():
+        out1 = ops.OcrAttendFn.apply(q1, key1.permute(0, 3, 1, 2), val, C ** -0.5)     # logit 8 * 256 / 16 = 128
+    row3 = val.float().permute(0, 2, 3, 1).reshape(B, K, C)[:, 3]
+    assert torch.equal(out1.float().permute(0, 2, 3, 1).reshape(B, H * W, C), row3[:, None, :].expand(B, H * W, C))
+    # gather: constant scores -> uniform weights 1 / (H W)
+    Cf = ops.OCR_GATHER_C
+    feats = torch.randn(B, H, W, Cf, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+    probs = torch.zeros(B, H, W, 16, device=DEV, dtype=torch.bfloat16).permute(0, 3, 1, 2)[:, :K]
+    with torch.no_grad():
+        ctx = ops.OcrGatherFn.apply(feats, probs, 1.0)
+    # the uniform weight 1 / 262144 = 2^-18 is exact in bf16: the result is the exact mean up to f32 summation order
+    mean = feats.float().mean(dim=(2, 3))                        # (B, Cf)
+    got = ctx.float().reshape(B, Cf, K)
+    assert float((got - mean[:, :, None]).abs().max()) < 1e-2 * float(mean.abs().max()) + 2e-3
