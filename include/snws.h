@@ -254,6 +254,11 @@ int snws_sn_apply_noalloc(const void* x, int64_t ldx, void* y, int64_t ldy, cons
 int snws_gemm1x1_supported(int N, int K);
 int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M, int N, int K,
                  void* stream);
+/* y += the same product (no bias; the f32 sum of the stored bf16 value and the new one, rounded once): the second half of
+ * a 1x1 convolution over torch.cat([a, b], 1) computed as w[:, :Ca] a + w[:, Ca:] b without building the concatenation
+ * (modeling/UNet3p_res_ocr_SNws.py:130), and a further contribution to an input gradient with several contributors
+ * (autograd's sum over the consumers of one tensor). */
+int snws_gemm1x1_acc(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int N, int K, void* stream);
 
 /* The two attention steps of the OCR head as fused streaming kernels (bf16 NHWC pixel tensors, float32 soft-max, every
  * small product on the matrix cores; per-class results leave as per-wave partial rows to be summed with snws_partial_sum).
@@ -263,6 +268,8 @@ int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, v
  *     snws_ocr_gather_fwd:   ctx_part [B][snws_ocr_tiles(HW, 1)][16][C]
  *     snws_ocr_gather_bwd:   dfeats = P * dctx, dprobs = scale * P * (feats . dctx - dot), dot[b][k] = <ctx, dctx>;
  *                            dctx bf16 [B][16][C] (rows >= K zero), dprobs bf16 [B][HW][16]
+ *     snws_ocr_gather_bwd_acc: the same with dfeats += (the feature map has other consumers whose shares of its gradient
+ *                            are already in dfeats: autograd's sum over consumers, done in place)
  *   _ObjectAttentionBlock.forward, modeling/UNet3p_res_ocr_SNws.py:87-100 (between f_pixel / f_object / f_down and f_up):
  *     out[b][p][c] = sum_k softmax_k(scale * q[b][p] . key[b][k]) * val[b][k][c]       (C = 256 key channels, K <= 16)
  *     snws_ocr_attend_fwd; key / val: bf16 [B][16][C], rows >= K zero
@@ -275,6 +282,9 @@ int snws_ocr_gather_fwd(const void* feats, int64_t ldf, const void* probs, int64
 int snws_ocr_gather_bwd(const void* feats, int64_t ldf, const void* probs, int64_t ldp, const float* stat_part, const void* dctx,
                         const float* dot, void* dfeats, int64_t lddf, void* dprobs, int B, int64_t HW, int C, int K, float scale,
                         void* stream);
+int snws_ocr_gather_bwd_acc(const void* feats, int64_t ldf, const void* probs, int64_t ldp, const float* stat_part,
+                            const void* dctx, const float* dot, void* dfeats, int64_t lddf, void* dprobs, int B, int64_t HW,
+                            int C, int K, float scale, void* stream);
 int snws_ocr_attend_fwd(const void* q, int64_t ldq, const void* key, const void* val, void* out, int64_t ldo, int B, int64_t HW,
                         int C, int K, float scale, void* stream);
 int snws_ocr_attend_bwd(const void* q, int64_t ldq, const void* dout, int64_t lddo, const void* key, const void* val, void* dq,

@@ -61,6 +61,17 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
 }
 
+// eight bf16 values + eight bf16 values, summed in f32 and rounded once
+__device__ __forceinline__ uint4 add_bf16x8(uint4 a, uint4 b) {
+  const unsigned x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+  unsigned r[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    r[e] = pack_bf16x2(__uint_as_float(x[e] << 16) + __uint_as_float(y[e] << 16),
+                       __uint_as_float(x[e] & 0xffff0000u) + __uint_as_float(y[e] & 0xffff0000u));
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
 // Vector access: V consecutive elements of type T as floats.  V*sizeof(T) is 16 bytes on the fast path, V=1 otherwise.
 template <typename T, int V>
 struct Vec;

@@ -45,6 +45,7 @@ struct GemmArgs {
   int64_t ldx, ldy, M;
   int N, K, ntN;       // ntN: channel tiles per pixel tile
   unsigned ntiles;
+  int accumulate;      // != 0: y += product (y holds a bf16 partial result or a gradient with several contributors)
 };
 
 // WM x WN waves, each MR x NR MFMA tiles of 16 x 16: workgroup tile = (WM*MR*16 = 256 pixels) x (WN*NR*16 channels)
@@ -153,8 +154,11 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(GemmArgs a) {
         const int row = q / CPR, c = q - row * CPR;
         const int64_t m = m0 + mr * 16 + row;
         const int n = n0 + c * 8;
-        if (q < TOTAL && m < a.M && n < a.N)
-          *reinterpret_cast<uint4*>(a.y + m * a.ldy + n) = *reinterpret_cast<const uint4*>(scr + row * G::RS + c * 16);
+        if (q < TOTAL && m < a.M && n < a.N) {
+          uint4 v = *reinterpret_cast<const uint4*>(scr + row * G::RS + c * 16);
+          if (a.accumulate) v = add_bf16x8(v, *reinterpret_cast<const uint4*>(a.y + m * a.ldy + n));   // kernel-uniform
+          *reinterpret_cast<uint4*>(a.y + m * a.ldy + n) = v;
+        }
       }
       wave_lds_sync();
     }
@@ -246,8 +250,9 @@ int pick_bn(int N) {
 
 extern "C" int snws_gemm1x1_supported(int N, int K) { return N >= 64 && N % 8 == 0 && K >= 64 && K % 64 == 0; }
 
-extern "C" int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M,
-                            int N, int K, void* stream) {
+namespace {
+int run_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M, int N, int K,
+                int accumulate, void* stream) {
   SNWS_CHECK_ARG(x && w && y, "snws_gemm1x1: NULL pointer");
   if (!snws_gemm1x1_supported(N, K)) SNWS_UNSUPPORTED("snws_gemm1x1: N = %d (>= 64, multiple of 8), K = %d (multiple of 64)", N, K);
   SNWS_CHECK_ARG(M >= 1 && ldx >= K && ldx % 8 == 0 && ldy >= N && ldy % 8 == 0, "snws_gemm1x1: bad sizes");
@@ -255,7 +260,7 @@ extern "C" int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const flo
                  "snws_gemm1x1: pointers must be 16-byte aligned");
   GemmArgs a{};
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y;
-  a.ldx = ldx; a.ldy = ldy; a.M = M; a.N = N; a.K = K;
+  a.ldx = ldx; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
   switch (pick_bn(N)) {
     case 256: return launch_gemm<2, 4, 8, 4>(a, st);
@@ -263,4 +268,15 @@ extern "C" int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const flo
     case 160: return launch_gemm<4, 2, 4, 5>(a, st);
     default: return launch_gemm<4, 2, 4, 4>(a, st);
   }
+}
+}  // namespace
+
+extern "C" int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M,
+                            int N, int K, void* stream) {
+  return run_gemm1x1(x, ldx, w, bias, y, ldy, M, N, K, 0, stream);
+}
+
+extern "C" int snws_gemm1x1_acc(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int N, int K,
+                                void* stream) {
+  return run_gemm1x1(x, ldx, w, nullptr, y, ldy, M, N, K, 1, stream);
 }

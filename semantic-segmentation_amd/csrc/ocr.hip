@@ -122,6 +122,19 @@ struct Tile {
       }
     }
   }
+  static __device__ __forceinline__ void store_add(bf16_t* img, int64_t ld, int64_t q0, int64_t p1, const LaneGeo& L, const unsigned char* t) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int64_t px = q0 + L.prow + 8 * jj;
+      if (px < p1) {
+        bf16_t* p = img + px * ld + 8 * L.oct;
+#pragma unroll
+        for (int j = 0; j < NSL; ++j)
+          *reinterpret_cast<uint4*>(p + 64 * j) = add_bf16x8(*reinterpret_cast<const uint4*>(t + (L.prow + 8 * jj) * RS + j * 128 + L.oct * 16),
+                                                             *reinterpret_cast<const uint4*>(p + 64 * j));
+      }
+    }
+  }
   // a dense [16][C] bf16 matrix (class rows) into a tile, by the whole workgroup
   static __device__ __forceinline__ void fill(unsigned char* t, const bf16_t* src) {
     for (int i = threadIdx.x; i < 16 * (C / 8); i += blockDim.x) {
@@ -396,6 +409,7 @@ struct GatherArgs {
   int64_t ldf, ldp, lddf, HW;
   int K, PT, Tn, Ts;
   float scale;
+  int accumulate;         // backward: dfeats += (it holds the other consumers' shares of the gradient)
 };
 
 // probabilities of this lane's four classes at pixel px (0 past the run or past K)
@@ -498,7 +512,8 @@ __global__ __launch_bounds__(OCR_THREADS) void ocr_gather_bwd_kernel(GatherArgs 
     for (int cb = 0; cb < C / 16; ++cb)
       T::put4(tile, L, cb, __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(T::tr(dctx_t, L, cb), pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0));
     wave_lds_sync();
-    T::store(dfi, a.lddf, q0, p1, L, tile);
+    if (a.accumulate) T::store_add(dfi, a.lddf, q0, p1, L, tile);   // kernel-uniform
+    else T::store(dfi, a.lddf, q0, p1, L, tile);
     wave_lds_sync();
   }
 }
@@ -600,9 +615,10 @@ extern "C" int snws_ocr_gather_fwd(const void* feats, int64_t ldf, const void* p
   return SNWS_OK;
 }
 
-extern "C" int snws_ocr_gather_bwd(const void* feats, int64_t ldf, const void* probs, int64_t ldp, const float* stat_part,
-                                   const void* dctx, const float* dot, void* dfeats, int64_t lddf, void* dprobs, int B, int64_t HW,
-                                   int C, int K, float scale, void* stream) {
+namespace {
+int run_ocr_gather_bwd(const void* feats, int64_t ldf, const void* probs, int64_t ldp, const float* stat_part,
+                       const void* dctx, const float* dot, void* dfeats, int64_t lddf, void* dprobs, int B, int64_t HW,
+                       int C, int K, float scale, int accumulate, void* stream) {
   if (C != GATHER_C) SNWS_UNSUPPORTED("snws_ocr_gather_bwd: %d feature channels (built for %d)", C, GATHER_C);
   SNWS_CHECK_ARG(feats && probs && stat_part && dctx && dot && dfeats && dprobs, "snws_ocr_gather_bwd: NULL pointer");
   SNWS_CHECK_ARG(B >= 1 && B <= 65535 && HW >= 1 && K >= 1 && K <= 16 && ldf >= C && ldf % 8 == 0 && lddf >= C && lddf % 8 == 0 &&
@@ -617,7 +633,21 @@ extern "C" int snws_ocr_gather_bwd(const void* feats, int64_t ldf, const void* p
   a.feats = (const bf16_t*)feats; a.probs = (const bf16_t*)probs; a.stat_part = stat_part; a.dctx = (const bf16_t*)dctx; a.dot = dot;
   a.dfeats = (bf16_t*)dfeats; a.dprobs = (bf16_t*)dprobs;
   a.ldf = ldf; a.ldp = ldp; a.lddf = lddf; a.HW = HW; a.K = K; a.PT = GATHER_PT; a.Ts = snws_ocr_tiles(HW, 0); a.scale = scale;
+  a.accumulate = accumulate;
   ocr_gather_bwd_kernel<GATHER_C><<<dim3((unsigned)cdiv64(HW, GATHER_PT), B), OCR_THREADS, LDS, (hipStream_t)stream>>>(a);
   SNWS_LAUNCH_CHECK("snws_ocr_gather_bwd");
   return SNWS_OK;
+}
+}  // namespace
+
+extern "C" int snws_ocr_gather_bwd(const void* feats, int64_t ldf, const void* probs, int64_t ldp, const float* stat_part,
+                                   const void* dctx, const float* dot, void* dfeats, int64_t lddf, void* dprobs, int B, int64_t HW,
+                                   int C, int K, float scale, void* stream) {
+  return run_ocr_gather_bwd(feats, ldf, probs, ldp, stat_part, dctx, dot, dfeats, lddf, dprobs, B, HW, C, K, scale, 0, stream);
+}
+
+extern "C" int snws_ocr_gather_bwd_acc(const void* feats, int64_t ldf, const void* probs, int64_t ldp, const float* stat_part,
+                                       const void* dctx, const float* dot, void* dfeats, int64_t lddf, void* dprobs, int B,
+                                       int64_t HW, int C, int K, float scale, void* stream) {
+  return run_ocr_gather_bwd(feats, ldf, probs, ldp, stat_part, dctx, dot, dfeats, lddf, dprobs, B, HW, C, K, scale, 1, stream);
 }

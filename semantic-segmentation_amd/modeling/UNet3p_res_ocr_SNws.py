@@ -108,8 +108,17 @@ class SpatialOCR_Module(nn.Module):
             FusedAway(),
             nn.Dropout2d(dropout))
 
+    def grad_share_ok(self, feats):
+        """True when every op of this module that reads `feats` takes part in shared-gradient accumulation
+        (ops.share_grad): f_pixel's first convolution and the two-product form of the 1x1 convolution below."""
+        return self.object_context_block.scale == 1 and ops.conv1x1_pair_ok(feats, feats, self.conv_bn_dropout[0])
+
     def forward(self, feats, proxy_feats):
         context = self.object_context_block(feats, proxy_feats)
+        conv, bn, _, drop = self.conv_bn_dropout
+        if ops.conv1x1_pair_ok(context, feats, conv):
+            # conv(cat([context, feats])) = W[:, :C] context + W[:, C:] feats: the concatenation is never built
+            return drop(bn(ops.Conv1x1PairFn.apply(context, feats, conv.weight)))
         return self.conv_bn_dropout(torch.cat([context, feats], 1))
 
 
@@ -186,9 +195,13 @@ class UNet3p_res_ocr_SNws(nn.Module):
             t = getattr(self, name + '_2')(getattr(self, name + '_1')(t))
             # encoder maps 1..4 feed the next stage's pool AND the decoder's skips: one shared gradient tensor
             enc[lvl] = t = ops.share_grad(t) if lvl < 5 else t
-        convu1 = full_scale_decoder(self, enc, pools)
+        # the finest decoder map feeds the auxiliary head and the OCR branch; the OCR features feed the region
+        # gather, the pixel branch of the attention and the final 1x1 convolution: one gradient tensor each
+        convu1 = ops.share_grad(full_scale_decoder(self, enc, pools))
         out_aux = self.aux_head(convu1)
         feats = self.conv3x3_ocr(convu1)
+        if ops.ocr_gather_ok(feats, out_aux) and self.ocr_distri_head.grad_share_ok(feats):
+            feats = ops.share_grad(feats)
         context = self.ocr_gather_head(feats, out_aux)
         feats = self.ocr_distri_head(feats, context)
         return head_conv(self.cls_head, feats, raw=self.raw_logits)

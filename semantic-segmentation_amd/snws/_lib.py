@@ -69,10 +69,12 @@ _SIGNATURES = {
     "snws_add_inplace": (c_int, [P, c_int64, P, c_int64, c_int, c_int64, c_int, P]),
     "snws_gemm1x1_supported": (c_int, [c_int, c_int]),
     "snws_gemm1x1": (c_int, [P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int, P]),
+    "snws_gemm1x1_acc": (c_int, [P, c_int64, P, P, c_int64, c_int64, c_int, c_int, P]),
     "snws_ocr_tiles": (c_int, [c_int64, c_int]),
     "snws_ocr_gather_stats": (c_int, [P, c_int64, P, c_int, c_int64, c_int, c_float, P]),
     "snws_ocr_gather_fwd": (c_int, [P, c_int64, P, c_int64, P, P, c_int, c_int64, c_int, c_int, c_float, P]),
     "snws_ocr_gather_bwd": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int, c_int64, c_int, c_int, c_float, P]),
+    "snws_ocr_gather_bwd_acc": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int, c_int64, c_int, c_int, c_float, P]),
     "snws_ocr_attend_fwd": (c_int, [P, c_int64, P, P, P, c_int64, c_int, c_int64, c_int, c_int, c_float, P]),
     "snws_ocr_attend_bwd": (c_int, [P, c_int64, P, c_int64, P, P, P, c_int64, P, P, c_int, c_int64, c_int, c_int, c_float, P]),
     "snws_sn_head_tiles": (c_int, [c_int64, c_int, c_int]),

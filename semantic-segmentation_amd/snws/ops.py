@@ -409,6 +409,7 @@ def fused_bwd_partials(s, dys, lddy):
 # the gradient arriving at the producer IS the parked tensor and raises otherwise.  A shared tensor carries no
 # SwitchNorm tags: a consumer's fused dgrad epilogue would reduce one share of the gradient, not the sum.
 GRAD_SHARE = os.environ.get("SNWS_GRAD_SHARE", "1") != "0"
+GRAD_SHARE_HITS = 0     # gradients added into a parked tensor so far (tests read it)
 
 
 class GradSlot:
@@ -467,6 +468,8 @@ def deliver_grad(slot, dx):
     if slot.buf is None:
         slot.buf = dx
         return dx
+    global GRAD_SHARE_HITS
+    GRAD_SHARE_HITS += 1
     add_inplace(slot.buf, dx)
     return None
 
@@ -501,6 +504,8 @@ def conv_backward(dy, prep, saved, weight, need_dx, need_dw, need_db, bias_key=N
                         _launch("conv_mfma_dgrad_k%d_kc%d" % (cfg.kh, 32 if cfg.O % 32 == 0 else 16), flops,
                                 "snws_conv_mfma_dgrad_acc", ctypes.byref(d), _ptr(dys), _ptr(prep.pack_dgrad), _ptr(a_), _stream())
                         done, gslot = True, None          # delivered: nothing to return
+                        global GRAD_SHARE_HITS
+                        GRAD_SHARE_HITS += 1
                     except L.SnwsUnsupported:
                         pass
             if not done:
@@ -1036,19 +1041,55 @@ def gemm1x1_ok(n_out, n_in):
     return GEMM_1X1 and bool(L.lib().snws_gemm1x1_supported(int(n_out), int(n_in)))
 
 
-def gemm1x1(x, w2d, bias=None, tag="gemm1x1_fwd"):
+def gemm1x1(x, w2d, bias=None, tag="gemm1x1_fwd", out=None, accumulate=False):
     """y[n, :, h, w] = w2d @ x[n, :, h, w] (+ bias) for a logical (N, K, H, W) bf16 tensor x with channels-last storage
-    (a channel slice of a wider buffer is fine) and a bf16 (C_out, K) matrix; returns the (N, C_out, H, W) result."""
+    (a channel slice of a wider buffer is fine) and a bf16 (C_out, K) matrix; returns (y, x's NHWC view, its pixel
+    stride).  out: an existing (N, C_out, H, W) NHWC bf16 tensor to write; with accumulate the product is added to it."""
     N, K, H, W = x.shape
     xs, ldx = as_nhwc(x)
     if ldx % 8 or xs.data_ptr() % 16:
         xs, ldx = _pad_channels(xs, ldx, K)
     n_out = w2d.shape[0]
-    y = new_nhwc(N, n_out, H, W, torch.bfloat16, x.device)
-    b32 = None if bias is None else (bias.detach() if bias.dtype == torch.float32 else bias.detach().float())
-    _launch(tag, 2.0 * N * H * W * n_out * K, "snws_gemm1x1", _ptr(xs), ldx, _ptr(w2d), _ptr(b32), _ptr(y), n_out,
-            N * H * W, n_out, K, _stream())
+    y = new_nhwc(N, n_out, H, W, torch.bfloat16, x.device) if out is None else out
+    ys, ldy = as_nhwc(y)
+    if ys.data_ptr() != y.data_ptr() or y.dtype != torch.bfloat16 or tuple(y.shape) != (N, n_out, H, W):
+        raise RuntimeError("gemm1x1: out must be an NHWC bf16 tensor of the result's shape")
+    if accumulate:
+        if bias is not None:
+            raise RuntimeError("gemm1x1: no bias in accumulate mode")
+        _launch(tag, 2.0 * N * H * W * n_out * K, "snws_gemm1x1_acc", _ptr(xs), ldx, _ptr(w2d), _ptr(ys), ldy, N * H * W, n_out,
+                K, _stream())
+    else:
+        b32 = None if bias is None else (bias.detach() if bias.dtype == torch.float32 else bias.detach().float())
+        _launch(tag, 2.0 * N * H * W * n_out * K, "snws_gemm1x1", _ptr(xs), ldx, _ptr(w2d), _ptr(b32), _ptr(ys), ldy,
+                N * H * W, n_out, K, _stream())
     return y, xs, ldx
+
+
+def slot_buffer(slot, shape, dtype):
+    """The tensor parked in a shared-gradient slot, if a kernel can add a (shape, dtype) gradient straight into it
+    (NHWC storage, 16-byte aligned pixel rows); else None."""
+    buf = slot.buf if slot is not None else None
+    if buf is None or buf.dtype != dtype or tuple(buf.shape) != tuple(shape):
+        return None
+    b_, ld = as_nhwc(buf)
+    if b_.data_ptr() != buf.data_ptr() or ld % 8 or b_.data_ptr() % 16:
+        return None
+    global GRAD_SHARE_HITS
+    GRAD_SHARE_HITS += 1
+    return buf
+
+
+def gemm1x1_dgrad(dyb, w_t, shape, slot):
+    """Input gradient of a wide 1x1 convolution (dyb bf16, w_t the transposed bf16 filter (C_in, C_out)), delivered to
+    the input's shared-gradient slot when it has one: a later contributor adds in the kernel's epilogue.  Returns what
+    the autograd function hands back for that input."""
+    tgt = slot_buffer(slot, shape, torch.bfloat16)
+    if tgt is not None:
+        gemm1x1(dyb, w_t, None, tag="gemm1x1_dgrad", out=tgt, accumulate=True)
+        return None
+    dx, _, _ = gemm1x1(dyb, w_t, None, tag="gemm1x1_dgrad")
+    return deliver_grad(slot, dx)
 
 
 def _gemm_1x1_ok(x, cfg):
@@ -1072,7 +1113,7 @@ class PlainConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         cfg = ConvCfg(weight.shape, 1, (weight.shape[2] - 1) // 2, 1, 1)
-        ctx.in_segs = input_segments(x)
+        ctx.in_segs, ctx.gslot = input_segments(x), grad_slot(x)
         ctx.gemm_w = None
         if ctx.in_segs is None and _gemm_1x1_ok(x, cfg):
             # a wide plain 1x1 convolution of an NHWC tensor IS a GEMM [pixels x C_in] x [C_in x C_out]: the wide-tile
@@ -1098,23 +1139,78 @@ class PlainConvFn(torch.autograd.Function):
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.gemm_w is not None:
             wb, (xs, ldx, (N, C, H, W), _) = ctx.gemm_w, ctx.saved
-            dys, lddy = as_nhwc(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16))
+            dyb = dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)
+            dys, lddy = as_nhwc(dyb)
             dx = dw = db = None
             if nx:
-                dx, dys, lddy = gemm1x1(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), wb.t().contiguous(),
-                                        None, tag="gemm1x1_dgrad")
+                dx = gemm1x1_dgrad(dyb, wb.t().contiguous(), (N, C, H, W), ctx.gslot)
             if nw or nb:
                 if lddy % 8 or dys.data_ptr() % 16:
                     dys = dys.contiguous(memory_format=torch.channels_last)
                     lddy = dys.shape[1]
                 dw, db = _conv_backward_weights(dys, lddy, ctx.prep, ctx.saved, weight, nw, nb, ctx.bias_key)
-            ctx.saved = ctx.gemm_w = None
+            ctx.saved = ctx.gemm_w = ctx.gslot = None
             return dx, None if dw is None else dw.to(weight.dtype), db
-        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs)
-        ctx.in_segs = None
+        dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        ctx.in_segs = ctx.gslot = None
         if dw is not None:
             dw = dw.to(weight.dtype)
         return dx, dw, db
+
+
+def conv1x1_pair_ok(a, b, conv):
+    """Can conv(torch.cat([a, b], 1)) for the bias-free 1x1 nn.Conv2d `conv` run as two products into one output?"""
+    if not (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 4 and a.shape[2:] == b.shape[2:]):
+        return False
+    w = conv.weight
+    Ca, Cb, O = a.shape[1], b.shape[1], w.shape[0]
+    return conv.bias is None and tuple(w.shape[1:]) == (Ca + Cb, 1, 1) and conv.stride == (1, 1) and conv.groups == 1 and \
+        all(gemm1x1_ok(n, k) for n, k in ((O, Ca), (O, Cb), (Ca, O), (Cb, O)))
+
+
+class Conv1x1PairFn(torch.autograd.Function):
+    """F.conv2d(torch.cat([a, b], 1), weight) for a 1x1 filter (modeling/UNet3p_res_ocr_SNws.py:130) as
+    weight[:, :Ca] a + weight[:, Ca:] b: the second product adds into the first one's output (snws_gemm1x1_acc), so the
+    concatenated tensor is never built, and in backward each input receives its own product (into its shared-gradient
+    slot when it has one)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        N, Ca, H, W = a.shape
+        Cb, O = b.shape[1], weight.shape[0]
+        w2 = weight.detach().reshape(O, Ca + Cb).to(torch.bfloat16)
+        wa, wb = w2[:, :Ca].contiguous(), w2[:, Ca:].contiguous()
+        y, as_, lda = gemm1x1(a, wa, None, tag="gemm1x1_fwd")
+        _, bs, ldb = gemm1x1(b, wb, None, tag="gemm1x1_fwd", out=y, accumulate=True)
+        ctx.saved = (as_, lda, bs, ldb, wa, wb, (N, Ca, Cb, O, H, W))
+        ctx.slots = (grad_slot(a), grad_slot(b))
+        ctx.save_for_backward(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        as_, lda, bs, ldb, wa, wb, (N, Ca, Cb, O, H, W) = ctx.saved
+        dyb = dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)
+        dys, lddy = as_nhwc(dyb)
+        if lddy % 8 or dys.data_ptr() % 16:
+            dyb = dyb.contiguous(memory_format=torch.channels_last)
+            dys, lddy = as_nhwc(dyb)
+        da = db = dw = None
+        # (b first: it is the tensor with other consumers, and its slot is more likely to hold a buffer already)
+        if ctx.needs_input_grad[1]:
+            db = gemm1x1_dgrad(dyb, wb.t().contiguous(), (N, Cb, H, W), ctx.slots[1])
+        if ctx.needs_input_grad[0]:
+            da = gemm1x1_dgrad(dyb, wa.t().contiguous(), (N, Ca, H, W), ctx.slots[0])
+        if ctx.needs_input_grad[2]:
+            halves = []
+            for xs, ldx, C in ((as_, lda, Ca), (bs, ldb, Cb)):
+                cfg = ConvCfg((O, C, 1, 1), 1, 0, 1, 1)
+                g, _ = _conv_backward_weights(dys, lddy, _PlainCfg(cfg), (xs, ldx, (N, C, H, W), True), None, True, False, None)
+                halves.append(g)
+            dw = torch.cat(halves, 1).to(weight.dtype)
+        ctx.saved = ctx.slots = None
+        return da, db, dw
 
 
 class SwitchNormFn(torch.autograd.Function):
@@ -1355,6 +1451,7 @@ class OcrGatherFn(torch.autograd.Function):
         c32 = torch.empty((B, 16, C), dtype=torch.float32, device=feats.device)
         L.call("snws_partial_sum_batched", _ptr(part), B, Tn, 16 * C, _ptr(c32), 0, st)
         ctx.saved = (fs, ldf, ps, ldp, stat, c32, (B, C, H, W), K, float(scale))
+        ctx.gslot = grad_slot(feats)
         return _from_rows(c32, K, feats.dtype)
 
     @staticmethod
@@ -1363,11 +1460,18 @@ class OcrGatherFn(torch.autograd.Function):
         ctx.saved = None
         d16 = _rows16(dctx, K)
         dot = (c32 * d16.float()).sum(-1).contiguous()
-        dfeats = new_nhwc(B, C, H, W, torch.bfloat16, dctx.device)
         dprobs = new_nhwc(B, 16, H, W, torch.bfloat16, dctx.device)
+        slot, ctx.gslot = ctx.gslot, None
+        tgt = slot_buffer(slot, (B, C, H, W), torch.bfloat16)
+        if tgt is not None:     # the feature map's other consumers have parked their gradient: add this share in the kernel
+            ts, ldt = as_nhwc(tgt)
+            _launch("ocr_gather_bwd", 4.0 * B * H * W * C, "snws_ocr_gather_bwd_acc", _ptr(fs), ldf, _ptr(ps), ldp, _ptr(stat),
+                    _ptr(d16), _ptr(dot), _ptr(ts), ldt, _ptr(dprobs), B, H * W, C, K, scale, _stream())
+            return None, dprobs[:, :K], None
+        dfeats = new_nhwc(B, C, H, W, torch.bfloat16, dctx.device)
         _launch("ocr_gather_bwd", 4.0 * B * H * W * C, "snws_ocr_gather_bwd", _ptr(fs), ldf, _ptr(ps), ldp, _ptr(stat), _ptr(d16),
                 _ptr(dot), _ptr(dfeats), C, _ptr(dprobs), B, H * W, C, K, scale, _stream())
-        return dfeats, dprobs[:, :K], None
+        return deliver_grad(slot, dfeats), dprobs[:, :K], None
 
 
 class OcrAttendFn(torch.autograd.Function):

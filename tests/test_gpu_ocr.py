@@ -94,3 +94,104 @@ def test_ocr_kernels_are_deterministic_and_reject_other_widths():
     z = torch.zeros(4096, device=DEV, dtype=torch.bfloat16)
     rc = lib.snws_ocr_attend_fwd(z.data_ptr(), 128, z.data_ptr(), z.data_ptr(), z.data_ptr(), 128, 1, 16, 128, 4, 1.0, None)
     assert rc == L.ERR_UNSUPPORTED
+
+
+def test_gemm1x1_acc_adds_into_its_destination():
+    """snws_gemm1x1_acc: y <- round(y + x w^T) (f32 sum of the stored bf16 value and the f32 product, rounded once)."""
+    from snws import ops
+    torch.manual_seed(5)
+    N, H, W, K, O = 2, 20, 13, 128, 192
+    x = _bf(torch.randn(N, H, W, K, device=DEV)).permute(0, 3, 1, 2)
+    w = _bf(torch.randn(O, K, device=DEV) / K ** 0.5)
+    y0 = _bf(torch.randn(N, H, W, O, device=DEV)).permute(0, 3, 1, 2)
+    y = y0.clone(memory_format=torch.preserve_format)
+    out, _, _ = ops.gemm1x1(x, w, None, out=y, accumulate=True)
+    assert out.data_ptr() == y.data_ptr()
+    ref = y0.double() + torch.einsum("nkhw,ok->nohw", x.double(), w.double())
+    assert l2err(y, ref) < 4e-3                    # one bf16 rounding of the sum
+    assert l2err(y, ref) < l2err(y0, ref) / 50
+
+
+def test_ocr_gather_bwd_acc_equals_separate_add():
+    from snws import ops
+    torch.manual_seed(6)
+    B, H, W, K, C = 2, 24, 20, 10, ops.OCR_GATHER_C
+    feats = _bf(torch.randn(B, H, W, C, device=DEV)).permute(0, 3, 1, 2)
+    probs = _bf(torch.randn(B, H, W, 16, device=DEV) * 2).permute(0, 3, 1, 2)[:, :K]
+    dctx = _bf(torch.randn(B, C, K, 1, device=DEV))
+    other = _bf(torch.randn(B, H, W, C, device=DEV)).permute(0, 3, 1, 2)      # another consumer's share of d feats
+    f1 = feats.detach().requires_grad_(True)
+    ops.OcrGatherFn.apply(f1, probs, 1.0).backward(dctx)
+    want = (f1.grad.float() + other.float()).to(torch.bfloat16)
+    f2 = feats.detach().requires_grad_(True)
+    shared = ops.share_grad(f2 * 1)                 # (a non-leaf producer, as in the model)
+    slot = ops.grad_slot(shared)
+    out = ops.OcrGatherFn.apply(shared, probs, 1.0)
+    slot.buf = other.clone(memory_format=torch.preserve_format)   # what an earlier consumer would have parked
+    parked = slot.buf
+    # the gather is the only real consumer here: feed the parked tensor to the producer by hand
+    (g,) = torch.autograd.grad(out, shared, dctx, allow_unused=True)
+    assert g is None                                # delivered in place
+    assert torch.equal(parked, want)
+
+
+@pytest.mark.parametrize("Ca,Cb,O", [(512, 512, 512), (128, 256, 192)])
+def test_conv1x1_pair_vs_float64_conv_of_concat(Ca, Cb, O):
+    """conv1x1(cat([a, b]), w) as two products into one output, and its three gradients; bars: 1e-2 (bf16 operands, one
+    extra bf16 rounding of the first partial product)."""
+    from snws import ops
+    torch.manual_seed(Ca + O)
+    N, H, W = 2, 18, 22
+    a = _bf(torch.randn(N, H, W, Ca, device=DEV)).permute(0, 3, 1, 2)
+    b = _bf(torch.randn(N, H, W, Cb, device=DEV)).permute(0, 3, 1, 2)
+    w = (torch.randn(O, Ca + Cb, 1, 1, device=DEV) / (Ca + Cb) ** 0.5)
+    dy = _bf(torch.randn(N, H, W, O, device=DEV)).permute(0, 3, 1, 2)
+    conv = torch.nn.Conv2d(Ca + Cb, O, 1, bias=False).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    assert ops.conv1x1_pair_ok(a, b, conv)
+    a1, b1 = a.detach().requires_grad_(True), b.detach().requires_grad_(True)
+    y = ops.Conv1x1PairFn.apply(a1, b1, conv.weight)
+    y.backward(dy)
+    a2, b2 = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    w2 = conv.weight.detach().to(torch.bfloat16).double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(torch.cat([a2, b2], 1), w2)
+    ref.backward(dy.double())
+    assert l2err(y, ref) < 1e-2
+    assert l2err(a1.grad, a2.grad) < 1e-2 and l2err(b1.grad, b2.grad) < 1e-2
+    assert l2err(conv.weight.grad, w2.grad) < 1e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2)])
+def test_res_ocr_shared_gradients_match_autograd_accumulation(dtype, tol):
+    """UNet3p_res_ocr_SNws with and without shared gradient buffers (decoder map -> auxiliary head + OCR branch; OCR
+    features -> region gather + pixel branch + final 1x1 convolution): same loss, same gradients to bf16 rounding of the
+    partial sums (median over parameters; the worst is bounded loosely - some gradients are tiny differences)."""
+    from modeling.UNet3p_res_ocr_SNws import UNet3p_res_ocr_SNws
+    from snws import ops
+    torch.manual_seed(3)
+    model = UNet3p_res_ocr_SNws(14, 16, 10, 1, 1).to(DEV).train()
+    model.compute_dtype = dtype
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    x = torch.randn(2, 14, 64, 64, device=DEV)
+    lab = torch.randint(0, 10, (2, 64, 64), device=DEV)
+    res = {}
+    saved = ops.GRAD_SHARE
+    try:
+        for share in (True, False):
+            ops.GRAD_SHARE = share
+            model.zero_grad(set_to_none=True)
+            hits0 = ops.GRAD_SHARE_HITS
+            loss = torch.nn.functional.cross_entropy(model(x).float(), lab)
+            loss.backward()
+            # decoder map: 1 later contributor; OCR features: 2; encoder maps, pooled copies and tap maps: many more
+            assert (ops.GRAD_SHARE_HITS - hits0 >= 10) == share, ops.GRAD_SHARE_HITS - hits0
+            res[share] = (loss.item(), [p.grad.float().clone() for p in model.parameters() if p.grad is not None])
+    finally:
+        ops.GRAD_SHARE = saved
+    assert abs(res[True][0] - res[False][0]) < 1e-3 * abs(res[False][0])
+    errs = sorted(l2err(a, b) for a, b in zip(res[True][1], res[False][1]))
+    assert len(errs) > 100
+    assert errs[len(errs) // 2] < tol and errs[-1] < 0.35, (errs[len(errs) // 2], errs[-1])
