@@ -336,6 +336,18 @@ int snws_bn_coeff(float* ctx, const float* pack, const float* gamma, float* runn
 int snws_bn_bwd_pack(const float* part, int T, int N, int C, float* packb, float* dgamma, float* dbeta, void* stream);
 int snws_bn_bwd_coeff(const float* ctx, float* ctxb, const float* packb, int N, int C, float count, int training,
                       void* stream);
+/* nn.Dropout2d after BatchNorm2d + ReLU (conv_bn_dropout, modeling/UNet3p_res_ocr_SNws.py:118-124) folded into the
+ * normalisation passes: post (N x C floats, >= 0) is the per-(image, channel) feature-dropout factor (0 or 1/(1-p)).
+ *   forward:  ... -> snws_bn_coeff -> snws_sn_apply_post:      y = post * act((x - mean) * scale + beta)
+ *   backward: snws_sn_bwd_reduce (on the unscaled gradient) -> snws_bn_bwd_pack_post (scales image n's partial sums by
+ *             post[n]) -> snws_bn_bwd_coeff -> snws_sn_bwd_apply_post: dx = A * post * dy' + B * x + K */
+int snws_sn_apply_post(const void* x, int64_t ldx, void* y, int64_t ldy, int dtype, const float* ctx, const float* beta,
+                       const float* post, int N, int64_t HW, int C, int relu, void* stream);
+int snws_sn_bwd_apply_post(const void* dy, int64_t lddy, const void* x, int64_t ldx, void* dx, int64_t lddx, int dtype,
+                           const float* ctx, const float* ctxb, const float* beta, const float* post, int N, int64_t HW,
+                           int C, int relu, void* stream);
+int snws_bn_bwd_pack_post(const float* part, int T, int N, int C, const float* post, float* packb, float* dgamma,
+                          float* dbeta, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Full-scale skip resampling - replaces nn.MaxPool2d(k,k,ceil_mode=True) / nn.Upsample(scale, bilinear,

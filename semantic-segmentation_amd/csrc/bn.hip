@@ -70,9 +70,11 @@ __global__ __launch_bounds__(256) void bn_coeff_kernel(float* __restrict__ ctx, 
   }
 }
 
+// post: optional per-(image, channel) multiplier of the forward's output (see snws_sn_apply_post): the partial sums of
+// image n were taken over the unscaled gradient and are scaled here
 __global__ __launch_bounds__(256) void bn_bwd_pack_kernel(const float* __restrict__ part, int T, int N, int C,
                                                           float* __restrict__ packb, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta) {
+                                                          float* __restrict__ dbeta, const float* __restrict__ post) {
   __shared__ double red[2][4][64];
   const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(256) void bn_bwd_pack_kernel(const float* __restric
     const int64_t rows = (int64_t)N * T;
     for (int64_t r = tl; r < rows; r += 4) {
       const float* p = part + (r * C + c) * 2;
-      s1 += (double)p[0];
-      s2 += (double)p[1];
+      const double pm = post ? (double)post[(r / T) * C + c] : 1.0;
+      s1 += pm * (double)p[0];
+      s2 += pm * (double)p[1];
     }
   }
   red[0][tl][cl] = s1;
@@ -142,8 +145,16 @@ extern "C" int snws_bn_coeff(float* ctx, const float* pack, const float* gamma, 
 extern "C" int snws_bn_bwd_pack(const float* part, int T, int N, int C, float* packb, float* dgamma, float* dbeta,
                                 void* stream) {
   SNWS_CHECK_ARG(part && packb && T >= 1 && N >= 1 && C >= 1, "snws_bn_bwd_pack: bad arguments");
-  bn_bwd_pack_kernel<<<cdiv(C, 64), 256, 0, (hipStream_t)stream>>>(part, T, N, C, packb, dgamma, dbeta);
+  bn_bwd_pack_kernel<<<cdiv(C, 64), 256, 0, (hipStream_t)stream>>>(part, T, N, C, packb, dgamma, dbeta, nullptr);
   SNWS_LAUNCH_CHECK("snws_bn_bwd_pack");
+  return SNWS_OK;
+}
+
+extern "C" int snws_bn_bwd_pack_post(const float* part, int T, int N, int C, const float* post, float* packb, float* dgamma,
+                                     float* dbeta, void* stream) {
+  SNWS_CHECK_ARG(part && packb && post && T >= 1 && N >= 1 && C >= 1, "snws_bn_bwd_pack_post: bad arguments");
+  bn_bwd_pack_kernel<<<cdiv(C, 64), 256, 0, (hipStream_t)stream>>>(part, T, N, C, packb, dgamma, dbeta, post);
+  SNWS_LAUNCH_CHECK("snws_bn_bwd_pack_post");
   return SNWS_OK;
 }
 

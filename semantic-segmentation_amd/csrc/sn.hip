@@ -248,7 +248,9 @@ __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restric
                                                               int64_t ldy, const T* __restrict__ res, int64_t ldr,
                                                               const float* __restrict__ ctx,
                                                               const float* __restrict__ beta, int N, int64_t HW, int C,
-                                                              int PT, SnMap m) {
+                                                              int PT, SnMap m, const float* __restrict__ post = nullptr) {
+  // post: optional non-negative multiplier per (image, channel) on the OUTPUT (a feature-dropout mask after the
+  // activation): act(z) * s = act(z * s) for s >= 0, so it is folded into the coefficients (no residual then)
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int64_t p0 = (int64_t)t * PT;
   const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
@@ -268,6 +270,11 @@ __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restric
       mu[v] = ctx[o.mean + i];
       sc[v] = ctx[o.scale + i];
       be[v] = beta[cg * V + v];
+      if (post) {
+        const float pm = post[i];
+        sc[v] *= pm;
+        be[v] *= pm;
+      }
     }
     const int64_t co = (int64_t)cg * V;
     int64_t p = p0 + prow;
@@ -613,7 +620,9 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
                                                                   const float* __restrict__ ctxb,
                                                                   const float* __restrict__ beta, int N, int64_t HW,
                                                                   int C, int PT, SnMap m,
-                                                                  T* __restrict__ dres = nullptr, int64_t lddr = 0) {
+                                                                  T* __restrict__ dres = nullptr, int64_t lddr = 0,
+                                                                  const float* __restrict__ post = nullptr) {
+  // post: the forward's per-(image, channel) output multiplier; the incoming gradient is scaled by it after the mask
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int64_t p0 = (int64_t)t * PT;
   const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
   for (int cg0 = 0; cg0 < m.CG; cg0 += m.cgb) {
     const int cg = cg0 + cgl;
     if (cg >= m.CG) continue;
-    float mu[V], sc[V], be[V], Bc[V], Kc[V];
+    float mu[V], sc[V], be[V], Bc[V], Kc[V], sg[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const int64_t i = (int64_t)n * C + cg * V + v;
@@ -638,6 +647,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
       be[v] = beta[cg * V + v];
       Bc[v] = ctxb[ob.B + i];
       Kc[v] = ctxb[ob.K + i];
+      sg[v] = post ? sc[v] * post[i] : sc[v];
     }
     const int64_t co = (int64_t)cg * V;
     int64_t p = p0 + prow;
@@ -666,8 +676,8 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
       }
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
-        g1[v] = fmaf(sc[v], g1[v], fmaf(Bc[v], a1[v], Kc[v]));
+        g0[v] = fmaf(sg[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
+        g1[v] = fmaf(sg[v], g1[v], fmaf(Bc[v], a1[v], Kc[v]));
       }
       VecNT<T, V>::store(on + p * lddx + co, g0);
       VecNT<T, V>::store(on + (p + m.PR) * lddx + co, g1);
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
       }
       if (DRES) VecNT<T, V>::store(rn + p * lddr + co, g0);
 #pragma unroll
-      for (int v = 0; v < V; ++v) g0[v] = fmaf(sc[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
+      for (int v = 0; v < V; ++v) g0[v] = fmaf(sg[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
       VecNT<T, V>::store(on + p * lddx + co, g0);
     }
   }
@@ -728,12 +738,12 @@ int run_stats(const void* x, int N, int64_t HW, int C, int64_t ldx, float* part,
 
 template <typename T, int V>
 int run_apply(const void* x, int64_t ldx, void* y, int64_t ldy, const void* res, int64_t ldr, const float* ctx,
-              const float* beta, int N, int64_t HW, int C, int relu, hipStream_t st) {
+              const float* beta, int N, int64_t HW, int C, int relu, hipStream_t st, const float* post = nullptr) {
   const SnMap m = sn_map(C, V);
   const int T_ = sn_tiles(N, HW, C);
   const int PT = (int)cdiv64(HW, T_);
   dim3 grid(T_, N);
-#define AP(R, S) sn_apply_kernel<T, V, R, S><<<grid, SN_THREADS, 0, st>>>((const T*)x, ldx, (T*)y, ldy, (const T*)res, ldr, ctx, beta, N, HW, C, PT, m)
+#define AP(R, S) sn_apply_kernel<T, V, R, S><<<grid, SN_THREADS, 0, st>>>((const T*)x, ldx, (T*)y, ldy, (const T*)res, ldr, ctx, beta, N, HW, C, PT, m, post)
   if (relu) { if (res) AP(true, true); else AP(true, false); }
   else { if (res) AP(false, true); else AP(false, false); }
 #undef AP
@@ -761,12 +771,12 @@ int run_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, con
 template <typename T, int V>
 int run_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* ym, int64_t ldy, void* dx,
                   int64_t lddx, const float* ctx, const float* ctxb, const float* beta, int N, int64_t HW, int C,
-                  int relu, hipStream_t st, void* dres = nullptr, int64_t lddr = 0) {
+                  int relu, hipStream_t st, void* dres = nullptr, int64_t lddr = 0, const float* post = nullptr) {
   const SnMap m = sn_map(C, V);
   const int T_ = sn_tiles(N, HW, C);
   const int PT = (int)cdiv64(HW, T_);
   dim3 grid(T_, N);
-#define BA(R, Y) sn_bwd_apply_kernel<T, V, R, Y><<<grid, SN_THREADS, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, (T*)dx, lddx, ctx, ctxb, beta, N, HW, C, PT, m)
+#define BA(R, Y) sn_bwd_apply_kernel<T, V, R, Y><<<grid, SN_THREADS, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, (T*)dx, lddx, ctx, ctxb, beta, N, HW, C, PT, m, nullptr, 0, post)
   if (dres)    // the caller checked relu && ym
     sn_bwd_apply_kernel<T, V, true, true, true><<<grid, SN_THREADS, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, (T*)dx, lddx, ctx, ctxb, beta, N, HW, C, PT, m, (T*)dres, lddr);
   else if (relu) { if (ym) BA(true, true); else BA(true, false); }
@@ -927,6 +937,39 @@ extern "C" int snws_sn_bwd_apply_res(const void* dy, int64_t lddy, const void* x
   if (can_vec<bf16_t>(C, {dy, x, y_for_mask, dx, dres}, {lddy, ldx, ldy, lddx, lddres}))
     return run_bwd_apply<bf16_t, 8>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
   return run_bwd_apply<bf16_t, 1>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
+}
+
+// The apply passes with a per-(image, channel) output multiplier `post` (N x C floats, >= 0) - a feature-dropout mask
+// that follows the normalisation (+ ReLU) folded into the same pass in both directions.
+extern "C" int snws_sn_apply_post(const void* x, int64_t ldx, void* y, int64_t ldy, int dtype, const float* ctx,
+                                  const float* beta, const float* post, int N, int64_t HW, int C, int relu, void* stream) {
+  SN_COMMON_CHECKS("snws_sn_apply_post");
+  SNWS_CHECK_ARG(x && y && ctx && beta && post, "snws_sn_apply_post: NULL pointer");
+  SNWS_CHECK_ARG(ldx >= C && ldy >= C, "snws_sn_apply_post: pixel stride smaller than C");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SNWS_F32) {
+    if (can_vec<float>(C, {x, y}, {ldx, ldy})) return run_apply<float, 4>(x, ldx, y, ldy, nullptr, 0, ctx, beta, N, HW, C, relu, st, post);
+    return run_apply<float, 1>(x, ldx, y, ldy, nullptr, 0, ctx, beta, N, HW, C, relu, st, post);
+  }
+  if (can_vec<bf16_t>(C, {x, y}, {ldx, ldy})) return run_apply<bf16_t, 8>(x, ldx, y, ldy, nullptr, 0, ctx, beta, N, HW, C, relu, st, post);
+  return run_apply<bf16_t, 1>(x, ldx, y, ldy, nullptr, 0, ctx, beta, N, HW, C, relu, st, post);
+}
+
+extern "C" int snws_sn_bwd_apply_post(const void* dy, int64_t lddy, const void* x, int64_t ldx, void* dx, int64_t lddx,
+                                      int dtype, const float* ctx, const float* ctxb, const float* beta, const float* post,
+                                      int N, int64_t HW, int C, int relu, void* stream) {
+  SN_COMMON_CHECKS("snws_sn_bwd_apply_post");
+  SNWS_CHECK_ARG(dy && x && dx && ctx && ctxb && beta && post, "snws_sn_bwd_apply_post: NULL pointer");
+  SNWS_CHECK_ARG(lddy >= C && ldx >= C && lddx >= C, "snws_sn_bwd_apply_post: pixel stride smaller than C");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SNWS_F32) {
+    if (can_vec<float>(C, {dy, x, dx}, {lddy, ldx, lddx}))
+      return run_bwd_apply<float, 4>(dy, lddy, x, ldx, nullptr, 0, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st, nullptr, 0, post);
+    return run_bwd_apply<float, 1>(dy, lddy, x, ldx, nullptr, 0, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st, nullptr, 0, post);
+  }
+  if (can_vec<bf16_t>(C, {dy, x, dx}, {lddy, ldx, lddx}))
+    return run_bwd_apply<bf16_t, 8>(dy, lddy, x, ldx, nullptr, 0, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st, nullptr, 0, post);
+  return run_bwd_apply<bf16_t, 1>(dy, lddy, x, ldx, nullptr, 0, dx, lddx, ctx, ctxb, beta, N, HW, C, relu, st, nullptr, 0, post);
 }
 
 // ------------------------------------------------------------------------------------------- no-allocation forward

@@ -6,8 +6,8 @@ What runs where: every Conv2dws -> SwitchNorm2d -> ReLU block, the residual bloc
 the full-scale skip decoder and all plain nn.Conv2d layers (1x1 and the 320 -> 512 3x3) go through the library's
 HIP kernels, and so do the OCR head's BatchNorm2d + ReLU pairs (blocks.HipBatchNorm2d; statistics of the local
 batch, as under the reference's DataParallel) and, in the bf16 tier, its two soft-max + batched-matmul attention
-steps (ops.OcrGatherFn / ops.OcrAttendFn).  Dropout2d is the stock torch op; the float32 tier's attention is stock
-torch too.
+steps (ops.OcrGatherFn / ops.OcrAttendFn); the Dropout2d after the last BatchNorm2d + ReLU rides on that pass's
+coefficients (HipBatchNorm2d.with_dropout).  The float32 tier's attention is stock torch.
 """
 import torch
 import torch.nn as nn
@@ -118,8 +118,8 @@ class SpatialOCR_Module(nn.Module):
         conv, bn, _, drop = self.conv_bn_dropout
         if ops.conv1x1_pair_ok(context, feats, conv):
             # conv(cat([context, feats])) = W[:, :C] context + W[:, C:] feats: the concatenation is never built
-            return drop(bn(ops.Conv1x1PairFn.apply(context, feats, conv.weight)))
-        return self.conv_bn_dropout(torch.cat([context, feats], 1))
+            return bn.with_dropout(ops.Conv1x1PairFn.apply(context, feats, conv.weight), drop)
+        return bn.with_dropout(conv(torch.cat([context, feats], 1)), drop)
 
 
 class GatedSpatialConv2d(_ConvNd):

@@ -144,7 +144,9 @@ class HipBatchNorm2d(nn.BatchNorm2d):
         self.fuse_relu, self.sync_stats, self.clamp_eps = fuse_relu, sync_stats, clamp_eps
         self.process_group = None
 
-    def forward(self, x):
+    def forward(self, x, post=None):
+        """post: optional (N, C) non-negative factors on the output per (image, channel): the mask of a Dropout2d that
+        follows, applied in the same pass (see with_dropout)."""
         self._check_input_dim(x)
         ops.require_gpu(x, "BatchNorm2d")
         momentum = 0.0 if self.momentum is None else self.momentum
@@ -153,7 +155,18 @@ class HipBatchNorm2d(nn.BatchNorm2d):
             if self.momentum is None:       # cumulative moving average
                 momentum = 1.0 / float(self.num_batches_tracked)
         return ops.BatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps,
-                                     self.training, self.fuse_relu, self.sync_stats, self.process_group, self.clamp_eps)
+                                     self.training, self.fuse_relu, self.sync_stats, self.process_group, self.clamp_eps, post)
+
+    def with_dropout(self, x, drop):
+        """drop(self(x)) for an nn.Dropout2d `drop` (modeling/UNet3p_res_ocr_SNws.py:118-124) in one pass per direction:
+        the mask is drawn as F.dropout2d draws it (one Bernoulli(1-p) per (image, channel) in x's dtype, divided by
+        1-p, so a seeded run sees the same mask) and rides on the normalisation coefficients."""
+        if not (drop.training and drop.p > 0.0):
+            return self(x)
+        if drop.p >= 1.0 or not ops.DROPOUT_FOLD:
+            return drop(self(x))
+        noise = x.new_empty((x.shape[0], x.shape[1], 1, 1)).bernoulli_(1.0 - drop.p).div_(1.0 - drop.p)
+        return self(x, post=noise)
 
 
 class FusedAway(nn.Identity):

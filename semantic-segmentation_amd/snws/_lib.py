@@ -101,6 +101,9 @@ _SIGNATURES = {
     "snws_bn_pack": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "snws_bn_coeff": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, c_float, c_float, c_int, c_int, P]),
     "snws_bn_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
+    "snws_bn_bwd_pack_post": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P]),
+    "snws_sn_apply_post": (c_int, [P, c_int64, P, c_int64, c_int, P, P, P, c_int, c_int64, c_int, c_int, P]),
+    "snws_sn_bwd_apply_post": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, P, c_int, c_int64, c_int, c_int, P]),
     "snws_bn_bwd_coeff": (c_int, [P, P, P, c_int, c_int, c_float, c_int, P]),
     "snws_tile_minmax_blocks": (c_int, [c_int64]),
     "snws_tile_minmax_scale": (c_int, [P, P, c_int, c_int, c_int64, P, P, P]),

@@ -918,10 +918,11 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
 
 # ------------------------------------------------------------------------------------------------ BatchNorm
 def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, sync=False, group=None,
-               clamp_eps=False):
+               clamp_eps=False, post=None):
     """nn.BatchNorm2d (optionally + ReLU) of the logical (N,C,H,W) tensor x on the SwitchNorm streaming kernels.
-    sync: all-reduce the packed moments over the process group (SynchronizedBatchNorm2d semantics).  Returns
-    (y, saved)."""
+    sync: all-reduce the packed moments over the process group (SynchronizedBatchNorm2d semantics).  post: optional
+    (N, C) float32 factors >= 0 applied to the output per (image, channel) - the feature-dropout mask of a
+    Dropout2d that follows - in the same pass.  Returns (y, saved)."""
     require_gpu(x, "BatchNorm2d")
     N, C, H, W = x.shape
     HW = H * W
@@ -955,11 +956,16 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
     L.call("snws_bn_coeff", _ptr(ctx), _ptr(pack), _ptr(g32), _ptr(running_mean), _ptr(running_var), N, HW, C, float(eps),
            float(momentum), int(use_batch), int(bool(clamp_eps)), st)
     y = new_nhwc(N, C, H, W, x.dtype, dev)
-    _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), C, None, 0, dt,
-            _ptr(ctx), _ptr(b32), N, HW, C, int(relu), st)
+    if post is not None:
+        post = post.detach().to(torch.float32).reshape(N, C).contiguous()
+        _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply_post", _ptr(xs), ldx, _ptr(y), C, dt,
+                _ptr(ctx), _ptr(b32), _ptr(post), N, HW, C, int(relu), st)
+    else:
+        _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), C, None, 0, dt,
+                _ptr(ctx), _ptr(b32), N, HW, C, int(relu), st)
     saved = dict(xs=xs, ldx=ldx, ctx=ctx, beta=b32, gamma=g32 if g32 is not None else torch.ones(C, dtype=torch.float32, device=dev),
                  relu=bool(relu), shape=(N, C, H, W), batch=use_batch, synced=synced, group=group,
-                 count=float(N * world * HW))
+                 count=float(N * world * HW), post=post)
     return y, saved
 
 
@@ -979,14 +985,22 @@ def bn_backward(dy, s):
     packb = torch.empty(2 * C, dtype=torch.float32, device=dev)
     dgamma = grad_out(grad_key(s["gamma"]), (C,), dev)
     dbeta = grad_out(grad_key(s["beta"]), (C,), dev)
-    L.call("snws_bn_bwd_pack", _ptr(part), T, N, C, _ptr(packb), _ptr(dgamma), _ptr(dbeta), st)
+    post = s.get("post")
+    if post is not None:
+        L.call("snws_bn_bwd_pack_post", _ptr(part), T, N, C, _ptr(post), _ptr(packb), _ptr(dgamma), _ptr(dbeta), st)
+    else:
+        L.call("snws_bn_bwd_pack", _ptr(part), T, N, C, _ptr(packb), _ptr(dgamma), _ptr(dbeta), st)
     if s["synced"]:
         _allreduce_sum(packb, s["group"])
     ctxb = torch.empty(lib.snws_sn_ctxb_floats(N, C), dtype=torch.float32, device=dev)
     L.call("snws_bn_bwd_coeff", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), N, C, float(s["count"]), int(s["batch"]), st)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
-    _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]),
-            s["ldx"], None, 0, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C, int(s["relu"]), st)
+    if post is not None:
+        _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply_post", _ptr(dys), lddy, _ptr(s["xs"]),
+                s["ldx"], _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), _ptr(post), N, HW, C, int(s["relu"]), st)
+    else:
+        _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy, _ptr(s["xs"]),
+                s["ldx"], None, 0, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), N, HW, C, int(s["relu"]), st)
     return dx, grad_fold(dgamma), grad_fold(dbeta)
 
 
@@ -994,9 +1008,10 @@ class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d.forward (+ optional ReLU) as one differentiable op on the HIP kernels."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, sync, group, clamp_eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, sync, group, clamp_eps,
+                post=None):
         y, saved = bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, sync, group,
-                              clamp_eps)
+                              clamp_eps, post)
         ctx.s = saved
         ctx.has = (gamma is not None, beta is not None)
         ctx.shapes = (None if gamma is None else gamma.shape, None if beta is None else beta.shape)
@@ -1007,7 +1022,7 @@ class BatchNormFn(torch.autograd.Function):
         dx, dg, db = bn_backward(dy, ctx.s)
         ctx.s = None
         return (dx, _view(dg, ctx.shapes[0]) if ctx.has[0] else None, _view(db, ctx.shapes[1]) if ctx.has[1] else None,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------ autograd
@@ -1158,9 +1173,13 @@ class PlainConvFn(torch.autograd.Function):
         return dx, dw, db
 
 
+PAIR_CONV = os.environ.get("SNWS_PAIR_CONV", "1") != "0"            # A/B switch of Conv1x1PairFn
+DROPOUT_FOLD = os.environ.get("SNWS_DROPOUT_FOLD", "1") != "0"      # A/B switch of HipBatchNorm2d.with_dropout's one-pass form
+
+
 def conv1x1_pair_ok(a, b, conv):
     """Can conv(torch.cat([a, b], 1)) for the bias-free 1x1 nn.Conv2d `conv` run as two products into one output?"""
-    if not (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 4 and a.shape[2:] == b.shape[2:]):
+    if not (PAIR_CONV and a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 4 and a.shape[2:] == b.shape[2:]):
         return False
     w = conv.weight
     Ca, Cb, O = a.shape[1], b.shape[1], w.shape[0]

@@ -195,3 +195,47 @@ def test_res_ocr_shared_gradients_match_autograd_accumulation(dtype, tol):
     errs = sorted(l2err(a, b) for a, b in zip(res[True][1], res[False][1]))
     assert len(errs) > 100
     assert errs[len(errs) // 2] < tol and errs[-1] < 0.35, (errs[len(errs) // 2], errs[-1])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_batchnorm_relu_dropout2d_in_one_pass(dtype, tol):
+    """HipBatchNorm2d.with_dropout == nn.Dropout2d(nn.ReLU(nn.BatchNorm2d(x))) (modeling/UNet3p_res_ocr_SNws.py:118-124)
+    for the mask a seeded F.dropout2d draws: output, input gradient, d gamma, d beta; whole (image, channel) maps are
+    zero exactly where torch zeroes them."""
+    from modeling.blocks import HipBatchNorm2d
+    torch.manual_seed(11)
+    N, C, H, W = 4, 64, 12, 10
+    x = torch.randn(N, C, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, C, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    bn = HipBatchNorm2d(C, fuse_relu=True).to(DEV).train()
+    ref_bn = torch.nn.BatchNorm2d(C).to(DEV).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) + 0.5)
+        bn.bias.copy_(torch.randn(C) * 0.3)
+        ref_bn.weight.copy_(bn.weight.double())
+        ref_bn.bias.copy_(bn.bias.double())
+    drop = torch.nn.Dropout2d(0.3).train()
+    x1 = x.detach().requires_grad_(True)
+    torch.manual_seed(77)
+    y = bn.with_dropout(x1, drop)
+    y.backward(dy)
+    # the reference composition; its mask comes from the same seeded draw in x's dtype
+    torch.manual_seed(77)
+    noise = x.new_empty((N, C, 1, 1)).bernoulli_(0.7).div_(0.7)
+    torch.manual_seed(77)
+    probe = torch.nn.functional.dropout2d(torch.ones_like(x), 0.3, True)
+    assert torch.equal(probe, noise.expand_as(probe).to(probe.dtype))           # F.dropout2d draws exactly this mask
+    x2 = x.detach().double().requires_grad_(True)
+    ref = torch.relu(ref_bn(x2)) * noise.double()
+    ref.backward(dy.double())
+    dropped = (noise.reshape(N, C) == 0)
+    assert dropped.any() and not dropped.all()
+    assert (y.float().abs().amax(dim=(2, 3))[dropped] == 0).all()
+    assert l2err(y, ref) < tol
+    assert l2err(x1.grad, x2.grad) < (tol if dtype == torch.float32 else 2e-2)
+    assert l2err(bn.weight.grad, ref_bn.weight.grad) < (tol if dtype == torch.float32 else 2e-2)
+    assert l2err(bn.bias.grad, ref_bn.bias.grad) < (tol if dtype == torch.float32 else 2e-2)
+    # p = 0 and evaluation mode: plain BatchNorm + ReLU
+    bn.eval()
+    assert torch.equal(bn.with_dropout(x, torch.nn.Dropout2d(0.0).train()), bn(x))
+    assert torch.equal(bn.with_dropout(x, drop.eval()), bn(x))
