@@ -191,6 +191,8 @@ class Resnet_BasicBlock(nn.Module):
         ops.require_gpu(x, "Resnet_BasicBlock")
         mf = x.dtype == torch.bfloat16
         c1, n1, c2, n2 = self.conv1, self.bn1, self.conv2, self.bn2
+        if self.downsample is None:
+            x = ops.share_grad(x)       # read by conv1 and by the residual add: one gradient tensor, summed in place
         t = ops.tag_sn_output(ops.ConvSnReluFn.apply(x, c1.weight, c1.bias, n1.weight, n1.bias, n1.mean_weight,
                                                      n1.var_weight, c1.prepared(mf and not c1.force_direct),
                                                      ops.SNParams(n1), True, None))

@@ -451,8 +451,9 @@ def grad_slot(x):
 def add_inplace(dst, src):
     """dst += src for logical (N, C, H, W) tensors with NHWC storage."""
     d, ldd = as_nhwc(dst)
-    if d.data_ptr() != dst.data_ptr():
-        raise RuntimeError("add_inplace: the destination is not NHWC storage")
+    if d.data_ptr() != dst.data_ptr():      # not NHWC storage (as_nhwc made a copy): the stock in-place add
+        dst.add_(src.to(dst.dtype))
+        return
     if src.dtype != dst.dtype:
         src = src.to(dst.dtype)
     s_, lds = as_nhwc(src)
@@ -1387,7 +1388,7 @@ class ConvSnAddReluFn(torch.autograd.Function):
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
         ctx.bias_key, ctx.in_segs, ctx.gslot = grad_key(bias), input_segments(x), grad_slot(x)
         ctx.shapes = (gamma.shape, beta.shape)
-        ctx.res_dtype = residual.dtype
+        ctx.res_dtype, ctx.res_slot = residual.dtype, grad_slot(residual)
         ctx.save_for_backward(weight)
         return y
 
@@ -1407,6 +1408,7 @@ class ConvSnAddReluFn(torch.autograd.Function):
         ctx.saved = None
         if dw is not None:
             dw = dw.to(weight.dtype)
+        dres, ctx.res_slot = deliver_grad(ctx.res_slot, dres), None
         return dx, dw, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, None, None, dres
 
 
