@@ -71,29 +71,51 @@ __global__ __launch_bounds__(256) void bn_coeff_kernel(float* __restrict__ ctx, 
 }
 
 // post: optional per-(image, channel) multiplier of the forward's output (see snws_sn_apply_post): the partial sums of
-// image n were taken over the unscaled gradient and are scaled here
-__global__ __launch_bounds__(256) void bn_bwd_pack_kernel(const float* __restrict__ part, int T, int N, int C,
-                                                          float* __restrict__ packb, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, const float* __restrict__ post) {
-  __shared__ double red[2][4][64];
+// image n were taken over the unscaled gradient and are scaled here.
+// 64 channels x 16 row lanes per workgroup, four rows in flight per thread (the rows are N*T short strided reads).
+constexpr int BP_LANES = 16;
+__global__ __launch_bounds__(64 * BP_LANES) void bn_bwd_pack_kernel(const float* __restrict__ part, int T, int N, int C,
+                                                                   float* __restrict__ packb, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, const float* __restrict__ post) {
+  __shared__ double red[2][BP_LANES][64];
   const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s1 = 0, s2 = 0;
   if (c < C) {
     const int64_t rows = (int64_t)N * T;
-    for (int64_t r = tl; r < rows; r += 4) {
-      const float* p = part + (r * C + c) * 2;
+    int64_t r = tl;
+    for (; r + 3 * BP_LANES < rows; r += 4 * BP_LANES) {
+      float2 v[4];
+      float pm[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ru = r + u * BP_LANES;
+        v[u] = *reinterpret_cast<const float2*>(part + (ru * C + c) * 2);
+        pm[u] = post ? post[(ru / T) * C + c] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s1 += (double)pm[u] * (double)v[u].x;
+        s2 += (double)pm[u] * (double)v[u].y;
+      }
+    }
+    for (; r < rows; r += BP_LANES) {
+      const float2 v = *reinterpret_cast<const float2*>(part + (r * C + c) * 2);
       const double pm = post ? (double)post[(r / T) * C + c] : 1.0;
-      s1 += pm * (double)p[0];
-      s2 += pm * (double)p[1];
+      s1 += pm * (double)v.x;
+      s2 += pm * (double)v.y;
     }
   }
   red[0][tl][cl] = s1;
   red[1][tl][cl] = s2;
   __syncthreads();
   if (tl == 0 && c < C) {
-    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    s1 = s2 = 0;
+#pragma unroll
+    for (int k = 0; k < BP_LANES; ++k) {     // fixed order: bit-reproducible
+      s1 += red[0][k][cl];
+      s2 += red[1][k][cl];
+    }
     packb[c] = (float)s1;
     packb[C + c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
@@ -145,7 +167,7 @@ extern "C" int snws_bn_coeff(float* ctx, const float* pack, const float* gamma, 
 extern "C" int snws_bn_bwd_pack(const float* part, int T, int N, int C, float* packb, float* dgamma, float* dbeta,
                                 void* stream) {
   SNWS_CHECK_ARG(part && packb && T >= 1 && N >= 1 && C >= 1, "snws_bn_bwd_pack: bad arguments");
-  bn_bwd_pack_kernel<<<cdiv(C, 64), 256, 0, (hipStream_t)stream>>>(part, T, N, C, packb, dgamma, dbeta, nullptr);
+  bn_bwd_pack_kernel<<<cdiv(C, 64), 64 * BP_LANES, 0, (hipStream_t)stream>>>(part, T, N, C, packb, dgamma, dbeta, nullptr);
   SNWS_LAUNCH_CHECK("snws_bn_bwd_pack");
   return SNWS_OK;
 }
@@ -153,7 +175,7 @@ extern "C" int snws_bn_bwd_pack(const float* part, int T, int N, int C, float* p
 extern "C" int snws_bn_bwd_pack_post(const float* part, int T, int N, int C, const float* post, float* packb, float* dgamma,
                                      float* dbeta, void* stream) {
   SNWS_CHECK_ARG(part && packb && post && T >= 1 && N >= 1 && C >= 1, "snws_bn_bwd_pack_post: bad arguments");
-  bn_bwd_pack_kernel<<<cdiv(C, 64), 256, 0, (hipStream_t)stream>>>(part, T, N, C, packb, dgamma, dbeta, post);
+  bn_bwd_pack_kernel<<<cdiv(C, 64), 64 * BP_LANES, 0, (hipStream_t)stream>>>(part, T, N, C, packb, dgamma, dbeta, post);
   SNWS_LAUNCH_CHECK("snws_bn_bwd_pack_post");
   return SNWS_OK;
 }
