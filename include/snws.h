@@ -387,6 +387,12 @@ int snws_upconv_bwd(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dt
  * with shift = bias.  bf16, ksize 3, k in {2,4,8,16}, C_out a multiple of 64 only (else SNWS_ERR_UNSUPPORTED: run
  * snws_upconv_fwd and snws_sn_stats). */
 int snws_upconv_stat_tiles(int H, int W);
+/* Which kernel family runs the staged bf16 3x3 forward (snws_upconv_fwd / snws_upconv_fwd_stats; no counterpart in the
+ * reference): 0 = interpolation on the vector ALUs, 2 = as small matrix products on the matrix cores, 1 (default; the
+ * environment variable SNWS_UPCONV_MFMA overrides it at first use) = matrix cores for k >= 4, vector ALUs for k = 2.
+ * The two families give the same products and differ only in the f32 summation order.  Returns the previous mode;
+ * any other argument only queries.  Process-wide. */
+int snws_upconv_fwd_mode(int mode);
 int snws_upconv_fwd_stats(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, int dtype, int N, int h,
                           int w, int C_out, int k, int ksize, float* stat_part, void* stream);
 

@@ -15,6 +15,7 @@
 // i1 = min(i0+1, in-1); taps that fall outside the image contribute zero (the conv's zero padding).
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -476,6 +477,443 @@ int launch_fwd_lds(const void* Z, int64_t ldz, void* y, int64_t ldy, const float
   }
 }
 
+// ---- the LDS-staged forward on the matrix cores (bf16, 3x3, k in {2,4,8,16}, 64-channel chunks).
+// y(p) = b + sum_ty sum_{(tx, r, c)} wy(py+ty-1; r) wx(px+tx-1; c) Z_{ty,tx}[r][c] is a small matrix product per run of
+// output pixels: a 4x4 block of outputs touches at most NRC x NRC source pixels per tap (3x3; 4x4 for k = 2), so per
+// filter row ty it is  D[64 channels][16 pixels] = Zrows[64][KIDX] * Wt[KIDX][16],  KIDX = 3 taps x NRC x NRC <= 32
+// (64 for k = 2).  Zrows comes straight from the staged footprint with the transposing LDS read (a contraction row =
+// one source pixel's 16 channels of one tap), Wt - products of two interpolation weights, multiples of 1/(4 k^2) -
+// is split into two bf16 halves that hold it EXACTLY (8 + 2 significant bits), so every product is exact and only the
+// f32 accumulation order differs from the separable kernels above.  Weights depend on the output position only
+// through its phase inside the source cell (and on the image border through zeroed taps): a workgroup walks a run of
+// 8x32 strips along one strip row, builds the weights once and keeps them in registers.  The interpolation work moves
+// from ~25 VALU operations per output to 1.5 matrix instructions per 16 outputs; what remains per output is the
+// rounding, the store and the statistics.
+typedef __attribute__((ext_vector_type(8))) __bf16 up_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float up_f32x4;
+typedef __attribute__((ext_vector_type(4))) short up_short4;
+typedef __attribute__((ext_vector_type(8))) short up_short8;
+
+__device__ __forceinline__ up_bf16x8 up_tr_frag(const unsigned char* p_lo, const unsigned char* p_hi) {
+  const up_short4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) up_short4*)p_lo);
+  const up_short4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) up_short4*)p_hi);
+  up_short8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(up_bf16x8, v);
+}
+
+template <int K>
+struct UpMfma {
+  static constexpr int NRC = K == 2 ? 4 : 3;            // source rows / columns four consecutive outputs of one tap touch
+  static constexpr int KIDX = 3 * NRC * NRC;            // contraction entries per filter row: (tx, source row, source column)
+  static constexpr int KS = (KIDX + 31) / 32;           // 16x16x32 steps
+  static constexpr int OUT_RS = 144;                    // bytes per pixel of the epilogue tile (128 + 16 pad)
+  static constexpr int OUT_BYTES = SEP_TH * SEP_TW * OUT_RS;
+  static constexpr int STAGE_BYTES = up_lds_bytes<K>();              // one filter row's footprint
+  static constexpr int BUF_BYTES = 3 * STAGE_BYTES;                   // all three filter rows of a strip
+  // two buffers (the next strip's copy in flight during this strip's work) where two workgroups per CU still fit;
+  // otherwise one buffer, which the epilogue tile then reuses
+  static constexpr int NBUF = 2 * BUF_BYTES + OUT_BYTES + 2048 <= 80 * 1024 ? 2 : 1;
+  static constexpr int OUT_OFF = NBUF == 2 ? 2 * BUF_BYTES : 0;
+  static constexpr int MAIN_BYTES = NBUF == 2 ? 2 * BUF_BYTES + OUT_BYTES : (BUF_BYTES > OUT_BYTES ? BUF_BYTES : OUT_BYTES);
+  static constexpr int LDS_BYTES = MAIN_BYTES + 4 * 64 * 2 * 4;
+};
+
+template <int K, int PH>
+__device__ __forceinline__ void upconv_mfma_body(const bf16_t* __restrict__ Z, int64_t ldz, bf16_t* __restrict__ y,
+                                                 int64_t ldy, const float* __restrict__ bias, float* __restrict__ stat,
+                                                 int h, int w, int Co, int tilesX, int tilesPerWg, unsigned char* smem) {
+  using G = UpStage<K, PH>;
+  using M = UpMfma<K>;
+  constexpr int LOG2K2 = K == 2 ? 2 : K == 4 ? 3 : K == 8 ? 4 : 5;      // log2(2K)
+  constexpr int NRC = M::NRC, KS = M::KS;
+  constexpr int PIXB = G::QS * 16;                                      // bytes per staged pixel
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunk = Co / 64;
+  const int cchunk = blockIdx.x % nchunk, xs = blockIdx.x / nchunk;
+  const int py0 = blockIdx.y * SEP_TH, n = blockIdx.z;
+  const int H = h * K, W = w * K;
+  const int base_lo = (py0 - PH * SEP_TH) / K + G::FLMIN;      // first staged source row (before clamping)
+  const unsigned char* zimg = reinterpret_cast<const unsigned char*>(Z + (int64_t)n * h * w * ldz + cchunk * 64);
+
+  // ---- lane geometry.  Matrix part: m = output pixel of a 4x4 block (row m >> 2, column m & 3), g = k octet.
+  // A wave owns the blocks (i, j): output rows 4i.. (i = 0, 1), output columns 4j.. with j = wave + 4 jj (jj = 0, 1);
+  // 16 columns apart the column phase repeats for every k, so one weight set serves both jj.
+  const int m = lane & 15, g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  auto decode = [&](int kidx, int& tx, int& r, int& c) -> bool {
+    const bool valid = kidx < M::KIDX;
+    tx = kidx / (NRC * NRC);
+    const int rem = kidx - tx * (NRC * NRC);
+    r = rem / NRC;
+    c = rem - r * NRC;
+    if (!valid) tx = r = c = 0;      // a real (finite) source value times a zero weight
+    return valid;
+  };
+  // column interpolation of this lane's output column for the three taps, relative to the block's first source column
+  int c0[3];           // first source column (relative to the 16-column group's origin) a block touches for tap tx
+  float wxc[3][NRC];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) {
+    const int q0 = 4 * wave + tx - 1;
+    c0[tx] = (2 * q0 + 1 - K) >> LOG2K2;
+    const int t2 = 2 * (q0 + (m & 3)) + 1 - K;
+    const int d = (t2 >> LOG2K2) - c0[tx];
+    const float lam = (float)(t2 & (2 * K - 1)) * (1.f / (float)(2 * K));
+#pragma unroll
+    for (int c = 0; c < NRC; ++c) wxc[tx][c] = c == d ? 1.f - lam : (c == d + 1 ? lam : 0.f);
+  }
+  // weights of this lane's entries (kidx = 32 ks + 8 g + e) per (filter row, block row), split hi + lo, packed in pairs
+  unsigned whi[3][2][KS][4], wlo[3][2][KS][4];
+  int etx[KS][8];      // tap column of each entry (for the border masks)
+  {
+    float wxe[KS][8];
+    int er[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int tx, r, c;
+        const bool valid = decode(ks * 32 + 8 * g + e, tx, r, c);
+        float wv = 0.f;
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+          for (int cc = 0; cc < NRC; ++cc) wv = (tx == t3 && c == cc) ? wxc[t3][cc] : wv;
+        wxe[ks][e] = valid ? wv : 0.f;
+        er[ks][e] = r;
+        etx[ks][e] = tx;
+      }
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        constexpr int dummy = 0; (void)dummy;
+        const int q0 = PH * SEP_TH + 4 * i + ty - 1;                 // block's first output row + tap shift (strip-relative)
+        const int r0 = (2 * q0 + 1 - K) >> LOG2K2;
+        const int t2 = 2 * (q0 + (m >> 2)) + 1 - K;
+        const int d = (t2 >> LOG2K2) - r0;
+        const float lam = (float)(t2 & (2 * K - 1)) * (1.f / (float)(2 * K));
+        const int qy = py0 + 4 * i + (m >> 2) + ty - 1;
+        const bool rowok = qy >= 0 && qy < H;                         // the conv's zero padding
+        float wyr[NRC];
+#pragma unroll
+        for (int r = 0; r < NRC; ++r) wyr[r] = !rowok ? 0.f : (r == d ? 1.f - lam : (r == d + 1 ? lam : 0.f));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            unsigned hi2[2], lo2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int e = 2 * e2 + u;
+              float wy = 0.f;
+#pragma unroll
+              for (int r = 0; r < NRC; ++r) wy = er[ks][e] == r ? wyr[r] : wy;
+              const float wv = wy * wxe[ks][e];                      // a multiple of 1/(4 K^2) below 1: at most 10 significant bits
+              const unsigned hb = __float_as_uint(wv) & 0xffff0000u;  // its top 8 significant bits ...
+              const float rest = wv - __uint_as_float(hb);            // ... and the rest (exact, at most 2 significant bits)
+              hi2[u] = hb >> 16;
+              lo2[u] = __float_as_uint(rest) >> 16;
+            }
+            whi[ty][i][ks][e2] = hi2[0] | (hi2[1] << 16);
+            wlo[ty][i][ks][e2] = lo2[0] | (lo2[1] << 16);
+          }
+      }
+  }
+  // transposing-read addresses of the Z operand: lane -> contraction row 32 ks + 8 g + 4 hq + tq, channels 4 tp .. 4 tp + 3
+  int ar[KS][2];                 // source row of that entry inside the block's footprint
+  int acol[2][KS][2];            // byte offset of (staged column, tap, channel quad) for jj = 0, 1 (set per strip)
+  int atx[KS][2], ac[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+      int tx, r, c;
+      decode(ks * 32 + 8 * g + 4 * hq + tq, tx, r, c);
+      ar[ks][hq] = r; atx[ks][hq] = tx; ac[ks][hq] = c;
+    }
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        int cc0 = 0;
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) cc0 = atx[ks][hq] == t3 ? c0[t3] : cc0;
+        int col = cc0 + (16 / K) * jj + 1 + ac[ks][hq];            // staged column 0 = source column (strip origin)/K - 1
+        col = col > G::CW - 1 ? G::CW - 1 : col;                     // (only entries with a zero weight get clamped)
+        acol[jj][ks][hq] = col * PIXB + atx[ks][hq] * 128 + tp * 8;
+      }
+
+  // epilogue mapping (as the kernel above): 8 lanes x 16 B = one pixel's 64 channels, a thread walks down the 8 rows
+  const int c8 = tid & 7, pxl = tid >> 3;
+  const int ch = cchunk * 64 + c8 * 8;
+  unsigned char* out_lds = smem + M::OUT_OFF;
+  float* st_lds = reinterpret_cast<float*>(smem + M::MAIN_BYTES);
+  float b4[4][4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b4[cb][e] = bias ? bias[cchunk * 64 + 16 * cb + 4 * g + e] : 0.f;
+  float sh[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) sh[v] = (stat && bias) ? bias[ch + v] : 0.f;
+
+  // ---- global -> LDS copy of a strip's footprint (all three filter rows) into buffer b
+  auto stage = [&](int tx_s, int b) {
+    const int col_lo = tx_s * SEP_TW / K - 1;
+    unsigned char* dst = smem + b * M::BUF_BYTES;
+#pragma unroll
+    for (int j = 0; j < G::JN; ++j) {
+      if (wave + 4 * j < G::NI) {
+        const int s = (wave + 4 * j) * 64 + lane;
+        const int q = s / G::QS, c = s - q * G::QS;
+        const int qr = q / G::CW, qc = q - qr * G::CW;
+        int row = base_lo + qr, col = col_lo + qc;
+        row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
+        col = col < 0 ? 0 : (col > w - 1 ? w - 1 : col);
+        const int tx = c >> 3, jc = c & 7;
+        const bool real = s < G::NS && c < 24;
+        const unsigned char* sp = zimg + (real ? (((int64_t)row * w + col) * ldz + (int64_t)tx * Co + jc * 8) * 2 : 0);
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+          up_glds16(sp + (int64_t)ty * 3 * Co * 2, dst + ty * M::STAGE_BYTES + (wave + 4 * j) * 1024);
+      }
+    }
+  };
+
+  const int t_begin = xs * tilesPerWg;
+  const int t_end = t_begin + tilesPerWg < tilesX ? t_begin + tilesPerWg : tilesX;
+  if (M::NBUF == 2) stage(t_begin, 0);
+  for (int tx_ = t_begin; tx_ < t_end; ++tx_) {
+    const int px0 = tx_ * SEP_TW;
+    const int buf = M::NBUF == 2 ? ((tx_ - t_begin) & 1) : 0;
+    if (M::NBUF == 1) {
+      __syncthreads();                                            // every wave is done reading the previous strip
+      stage(tx_, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                              // this strip's footprint has landed for every wave
+    if (M::NBUF == 2 && tx_ + 1 < t_end) stage(tx_ + 1, buf ^ 1);  // in flight during the matrix work and the epilogue
+    const unsigned char* zb = smem + buf * M::BUF_BYTES;
+    // taps that fall outside the image columns (the strip touches the left / right border): zero their weights
+    const bool edge = px0 == 0 || px0 + SEP_TW >= W;            // block-uniform
+    unsigned cmask[2][KS][4];
+    if (edge) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        bool ok[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const int qx = px0 + 16 * jj + 4 * wave + (m & 3) + tx - 1;
+          ok[tx] = qx >= 0 && qx < W;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            bool o0 = false, o1 = false;
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+              o0 = etx[ks][2 * e2] == t3 ? ok[t3] : o0;
+              o1 = etx[ks][2 * e2 + 1] == t3 ? ok[t3] : o1;
+            }
+            cmask[jj][ks][e2] = (o0 ? 0xffffu : 0u) | (o1 ? 0xffff0000u : 0u);
+          }
+      }
+    }
+
+    up_f32x4 acc[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[i][jj][cb] = up_f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const unsigned char* zs = zb + ty * M::STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        constexpr int dummy = 0; (void)dummy;
+        const int rr0 = up_fl<K>(PH * SEP_TH + 4 * i + ty - 1) - G::FLMIN;      // staged row of the block's first source row
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          int rowb[2];
+#pragma unroll
+          for (int hq = 0; hq < 2; ++hq) {
+            int rr = rr0 + ar[ks][hq];
+            rr = rr > G::R - 1 ? G::R - 1 : rr;                   // (only entries with a zero weight get clamped)
+            rowb[hq] = rr * (G::CW * PIXB);
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            unsigned h4[4], l4[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+              h4[e2] = whi[ty][i][ks][e2];
+              l4[e2] = wlo[ty][i][ks][e2];
+              if (edge) { h4[e2] &= cmask[jj][ks][e2]; l4[e2] &= cmask[jj][ks][e2]; }
+            }
+            const up_bf16x8 wh = __builtin_bit_cast(up_bf16x8, make_uint4(h4[0], h4[1], h4[2], h4[3]));
+            const up_bf16x8 wl = __builtin_bit_cast(up_bf16x8, make_uint4(l4[0], l4[1], l4[2], l4[3]));
+            const unsigned char* p0 = zs + rowb[0] + acol[jj][ks][0];
+            const unsigned char* p1 = zs + rowb[1] + acol[jj][ks][1];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+              const up_bf16x8 zf = up_tr_frag(p0 + cb * 32, p1 + cb * 32);
+              acc[i][jj][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, wh, acc[i][jj][cb], 0, 0, 0);
+              acc[i][jj][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, wl, acc[i][jj][cb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- accumulators (+ bias) -> bf16 tile in LDS: lane holds pixel m of block (i, j) and channels 16 cb + 4 g + (0..3)
+    // (two buffers: the tile has its own region, and the barrier at the top of this iteration ordered the previous
+    //  strip's readers before these writes; one buffer: the tile reuses it once every wave is done reading)
+    if (M::NBUF == 1) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int qp = (4 * i + (m >> 2)) * SEP_TW + 4 * (wave + 4 * jj) + (m & 3);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          const up_f32x4 v = acc[i][jj][cb];
+          *reinterpret_cast<uint2*>(out_lds + qp * M::OUT_RS + (16 * cb + 4 * g) * 2) =
+              make_uint2(pack_bf16x2(v[0] + b4[cb][0], v[1] + b4[cb][1]), pack_bf16x2(v[2] + b4[cb][2], v[3] + b4[cb][3]));
+        }
+      }
+    __syncthreads();
+
+    // ---- stores (8 lanes x 16 B = one pixel's 64 channels) and the optional per-channel partial moments
+    const int px = px0 + pxl;
+    const bool col_ok = px < W;
+    float S[8], Q[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) S[v] = Q[v] = 0.f;
+#pragma unroll
+    for (int py = 0; py < SEP_TH; ++py) {
+      if (col_ok && py0 + py < H) {
+        const uint4 v = *reinterpret_cast<const uint4*>(out_lds + (py * SEP_TW + pxl) * M::OUT_RS + c8 * 16);
+        *reinterpret_cast<uint4*>(y + (((int64_t)n * H + py0 + py) * W + px) * ldy + ch) = v;
+        if (stat) {
+          const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f0 = __uint_as_float(u[e] << 16) - sh[2 * e];
+            const float f1 = __uint_as_float(u[e] & 0xffff0000u) - sh[2 * e + 1];
+            S[2 * e] += f0; Q[2 * e] += f0 * f0;
+            S[2 * e + 1] += f1; Q[2 * e + 1] += f1 * f1;
+          }
+        }
+      }
+    }
+    if (stat) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+          S[e] += __shfl_xor(S[e], o, 64);
+          Q[e] += __shfl_xor(Q[e], o, 64);
+        }
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          st_lds[(wave * 64 + lane * 8 + e) * 2] = S[e];
+          st_lds[(wave * 64 + lane * 8 + e) * 2 + 1] = Q[e];
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          s += st_lds[(wv * 64 + tid) * 2];
+          q += st_lds[(wv * 64 + tid) * 2 + 1];
+        }
+        const int64_t tile = (int64_t)blockIdx.y * tilesX + tx_;
+        const int64_t T = (int64_t)gridDim.y * tilesX;
+        float* o = stat + (((int64_t)n * T + tile) * Co + cchunk * 64 + tid) * 2;
+        o[0] = s;
+        o[1] = q;
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void upconv_fwd_mfma_kernel(const bf16_t* __restrict__ Z, int64_t ldz,
+                                                                bf16_t* __restrict__ y, int64_t ldy,
+                                                                const float* __restrict__ bias, float* __restrict__ stat,
+                                                                int h, int w, int Co, int tilesX, int tilesPerWg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char up_smem[];
+  if constexpr (K == 16) {
+    if (blockIdx.y & 1) upconv_mfma_body<K, 1>(Z, ldz, y, ldy, bias, stat, h, w, Co, tilesX, tilesPerWg, up_smem);
+    else upconv_mfma_body<K, 0>(Z, ldz, y, ldy, bias, stat, h, w, Co, tilesX, tilesPerWg, up_smem);
+  } else {
+    upconv_mfma_body<K, 0>(Z, ldz, y, ldy, bias, stat, h, w, Co, tilesX, tilesPerWg, up_smem);
+  }
+}
+
+template <int K>
+int launch_fwd_mfma_k(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, float* stat, int N, int h, int w,
+                      int Co, hipStream_t st) {
+  constexpr int LDS = UpMfma<K>::LDS_BYTES;
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_fwd_mfma_kernel<K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      snws_set_error("upconv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    if (attr_set) attr_set->store(true, std::memory_order_release);
+  }
+  const int H = h * K, W = w * K;
+  const int tilesX = cdiv(W, SEP_TW), tilesY = cdiv(H, SEP_TH);
+  // a workgroup walks a run of strips along x (its weights stay in registers); short runs when the map is small
+  const int64_t rows = (int64_t)(Co / 64) * tilesY * N;
+  int xsplits = (int)cdiv64(2048, rows);
+  if (xsplits > tilesX) xsplits = tilesX;
+  if (xsplits < 1) xsplits = 1;
+  const int tilesPerWg = cdiv(tilesX, xsplits);
+  xsplits = cdiv(tilesX, tilesPerWg);
+  dim3 grid((unsigned)((Co / 64) * xsplits), (unsigned)tilesY, (unsigned)N);
+  upconv_fwd_mfma_kernel<K><<<grid, 256, LDS, st>>>((const bf16_t*)Z, ldz, (bf16_t*)y, ldy, bias, stat, h, w, Co, tilesX, tilesPerWg);
+  return SNWS_OK;
+}
+
+int launch_fwd_mfma(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, float* stat, int N, int h, int w,
+                    int Co, int k, hipStream_t st) {
+  switch (k) {
+    case 2: return launch_fwd_mfma_k<2>(Z, ldz, y, ldy, bias, stat, N, h, w, Co, st);
+    case 4: return launch_fwd_mfma_k<4>(Z, ldz, y, ldy, bias, stat, N, h, w, Co, st);
+    case 8: return launch_fwd_mfma_k<8>(Z, ldz, y, ldy, bias, stat, N, h, w, Co, st);
+    default: return launch_fwd_mfma_k<16>(Z, ldz, y, ldy, bias, stat, N, h, w, Co, st);
+  }
+}
+
+// The matrix form wins for k >= 4 (139 / 169 / 243 us against 194 / 238 / 344 us per launch for k = 4 / 8 / 16 on the
+// decoder's shapes); for k = 2 a 4-pixel run touches 4 source pixels per axis, the contraction doubles and the VALU form
+// stays ahead.  SNWS_UPCONV_MFMA=0 / 2 force the VALU / the matrix form for every k (A/B measurements).
+std::atomic<int> g_upconv_mode{-1};
+bool upconv_mfma_on(int k) {
+  int mode = g_upconv_mode.load(std::memory_order_relaxed);
+  if (mode < 0) {
+    mode = getenv("SNWS_UPCONV_MFMA") ? atoi(getenv("SNWS_UPCONV_MFMA")) : 1;
+    g_upconv_mode.store(mode, std::memory_order_relaxed);
+  }
+  return mode == 2 || (mode == 1 && k >= 4);
+}
+
 // Backward: one thread per (source pixel, channel group) for ALL taps: every dy value of the (2k+2)^2 window is
 // loaded once and scattered into the taps' register accumulators with separable weights.
 template <typename TZ, typename TY, int V, int KH>
@@ -694,7 +1132,8 @@ extern "C" int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy,
   static const bool no_sep = getenv("SNWS_UPCONV_GATHER") != nullptr;   // A/B switch: the per-pixel gather kernel
   static const bool no_lds = getenv("SNWS_UPCONV_NOLDS") != nullptr;    // A/B switch: the kernels without LDS staging
   if (!no_sep && !no_lds && lds_fwd_ok(dtype, Z, ldz, y, ldy, N, h, w, C_out, k, ksize)) {
-    if (int rc = launch_fwd_lds(Z, ldz, y, ldy, bias, nullptr, N, h, w, C_out, k, st)) return rc;
+    if (int rc = upconv_mfma_on(k) ? launch_fwd_mfma(Z, ldz, y, ldy, bias, nullptr, N, h, w, C_out, k, st)
+                                  : launch_fwd_lds(Z, ldz, y, ldy, bias, nullptr, N, h, w, C_out, k, st)) return rc;
     SNWS_LAUNCH_CHECK("snws_upconv_fwd");
     return SNWS_OK;
   }
@@ -721,6 +1160,13 @@ extern "C" int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy,
   return SNWS_OK;
 }
 
+extern "C" int snws_upconv_fwd_mode(int mode) {
+  upconv_mfma_on(2);                    // (reads the environment on first use)
+  const int prev = g_upconv_mode.load(std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 2) g_upconv_mode.store(mode, std::memory_order_relaxed);
+  return prev;
+}
+
 extern "C" int snws_upconv_stat_tiles(int H, int W) { return cdiv(H, SEP_TH) * cdiv(W, SEP_TW); }
 
 extern "C" int snws_upconv_fwd_stats(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, int dtype,
@@ -731,7 +1177,8 @@ extern "C" int snws_upconv_fwd_stats(const void* Z, int64_t ldz, void* y, int64_
   if (!lds_fwd_ok(dtype, Z, ldz, y, ldy, N, h, w, C_out, k, ksize))
     SNWS_UNSUPPORTED("snws_upconv_fwd_stats: needs bf16, a 3x3 filter, k in {2,4,8,16}, C_out a multiple of 64 and "
                      "16-byte aligned tensors (got dtype %d, ksize %d, k %d, C_out %d)", dtype, ksize, k, C_out);
-  if (int rc = launch_fwd_lds(Z, ldz, y, ldy, bias, stat_part, N, h, w, C_out, k, (hipStream_t)stream)) return rc;
+  if (int rc = upconv_mfma_on(k) ? launch_fwd_mfma(Z, ldz, y, ldy, bias, stat_part, N, h, w, C_out, k, (hipStream_t)stream)
+                                : launch_fwd_lds(Z, ldz, y, ldy, bias, stat_part, N, h, w, C_out, k, (hipStream_t)stream)) return rc;
   SNWS_LAUNCH_CHECK("snws_upconv_fwd_stats");
   return SNWS_OK;
 }

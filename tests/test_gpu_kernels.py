@@ -1576,6 +1576,60 @@ np.savez(sys.argv[1], **out)
 
 
 @pytest.mark.gpu
+def test_upconv_matrix_form_matches_vector_form():
+    """The staged forward as small matrix products (snws_upconv_fwd_mode 2) against the same forward on the vector ALUs
+    (mode 0), every k, strips cut by all four image borders, one-pixel sources, 128 channels, with and without bias:
+    both forms take exact products of the same bf16 values and exactly represented interpolation weights, so they differ
+    by the f32 summation order only - at most one bf16 unit in the last place of the output; the per-strip statistics
+    must match the moments of the y each form stored.  A constant source map must come out exactly (weights sum to 1)."""
+    from snws import _lib as L
+    lib = L.lib()
+    prev = lib.snws_upconv_fwd_mode(-1)
+    try:
+        torch.manual_seed(4)
+        for k, h, w, Co, with_bias in ((2, 3, 5, 64, True), (2, 20, 37, 64, False), (4, 3, 2, 64, True), (4, 9, 17, 128, True),
+                                       (8, 2, 5, 64, True), (8, 5, 9, 64, False), (16, 1, 3, 64, True), (16, 3, 4, 128, True),
+                                       (2, 1, 1, 64, True), (16, 1, 1, 64, True), (4, 16, 24, 64, True), (8, 8, 12, 64, True)):
+            N, H, W = 2, h * k, w * k
+            Z = torch.randn(N, h, w, 9 * Co, device=DEV).to(torch.bfloat16)
+            b = torch.randn(Co, device=DEV) if with_bias else None
+            T = lib.snws_upconv_stat_tiles(H, W)
+            ys, parts = [], []
+            for mode in (0, 2):
+                lib.snws_upconv_fwd_mode(mode)
+                y = torch.full((N, H, W, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
+                part = torch.full((N, T, Co, 2), float("nan"), device=DEV)
+                L.call("snws_upconv_fwd_stats", Z.data_ptr(), 9 * Co, y.data_ptr(), Co, None if b is None else b.data_ptr(), 1,
+                       N, h, w, Co, k, 3, part.data_ptr(), 0)
+                y2 = torch.empty_like(y)
+                L.call("snws_upconv_fwd", Z.data_ptr(), 9 * Co, y2.data_ptr(), Co, None if b is None else b.data_ptr(), 1, N,
+                       h, w, Co, k, 3, 0)
+                assert torch.equal(y, y2), (k, h, w, mode)
+                d = y.double() - (0 if b is None else b.double())
+                s_ref = torch.stack([d.sum((1, 2)), (d * d).sum((1, 2))], -1)
+                assert torch.isfinite(part).all() and torch.isfinite(y.float()).all()
+                assert float((part.double().sum(1) - s_ref).abs().max()) < 1e-5 * float(s_ref.abs().max()), (k, h, w, mode)
+                ys.append(y.float())
+            diff = (ys[0] - ys[1]).abs()
+            assert float((diff / ys[0].abs().clamp_min(1e-3)).max()) <= 2 ** -7, (k, h, w, float(diff.max()))
+            assert float((diff > 0).float().mean()) < 0.05, (k, h, w)          # and almost every value is identical
+        # constant maps: every tap map constant c_t -> interior outputs are exactly sum_t c_t (+ bias)
+        for k in (2, 4, 8, 16):
+            h = w = 6
+            Co = 64
+            cvals = torch.tensor([0.5, -1.25, 2.0, 0.75, 3.0, -0.5, 1.5, 0.25, -2.0], device=DEV)
+            Z = cvals.repeat_interleave(Co).to(torch.bfloat16).expand(1, h, w, 9 * Co).contiguous()
+            for mode in (0, 2):
+                lib.snws_upconv_fwd_mode(mode)
+                y = torch.empty(1, h * k, w * k, Co, device=DEV, dtype=torch.bfloat16)
+                L.call("snws_upconv_fwd", Z.data_ptr(), 9 * Co, y.data_ptr(), Co, None, 1, 1, h, w, Co, k, 3, 0)
+                inner = y[:, 1:-1, 1:-1].float()
+                assert float((inner - float(cvals.sum())).abs().max()) == 0.0, (k, mode)
+    finally:
+        lib.snws_upconv_fwd_mode(prev)
+
+
+@pytest.mark.gpu
 def test_upconv_separable_backward_matches_gather_backward():
     """The separable backward (bf16, 3x3; window columns split over 1/2/4/8 lanes for k = 2/4/8/16) against the
     per-source-pixel gather kernel (SNWS_UPCONV_BWD_GATHER=1, read once per process, hence the child process): the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small target for rocprofv3 --pmc passes: runs ONE family of kernels a few times on the headline shapes.
-    python tools/pmc_target.py conv|wgrad|sn|hist"""
+    python tools/pmc_target.py conv|wgrad|sn|hist|upconv"""
 import os
 import sys
 
@@ -34,6 +34,14 @@ elif what == "sn":
     for _ in range(3):
         y, saved = ops.sn_forward(x, p, True)
         ops.sn_backward(dy, saved)
+elif what == "upconv":
+    # conv(upsample_k(x)) for every scale of the decoder, 512^2 outputs, forward and backward
+    blk = ConvSnRelu(320, 64).to(DEV).train()
+    for k in (2, 4, 8, 16):
+        x = torch.randn(N, 512 // k, 512 // k, 320, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2).requires_grad_(True)
+        for _ in range(2):
+            y = blk.on_upsampled(x, k)
+            y.backward(torch.ones_like(y))
 elif what == "hist":
     from utils.metrics import Evaluator
     gt = torch.randint(0, 10, (16, 2748, 2748), device=DEV).float()
