@@ -388,10 +388,9 @@ int snws_upconv_bwd(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dt
  * snws_upconv_fwd and snws_sn_stats). */
 int snws_upconv_stat_tiles(int H, int W);
 /* Which kernel family runs the staged bf16 3x3 forward (snws_upconv_fwd / snws_upconv_fwd_stats; no counterpart in the
- * reference): 0 = interpolation on the vector ALUs, 2 = as small matrix products on the matrix cores, 1 (default; the
- * environment variable SNWS_UPCONV_MFMA overrides it at first use) = matrix cores for k >= 4, vector ALUs for k = 2.
- * The two families give the same products and differ only in the f32 summation order.  Returns the previous mode;
- * any other argument only queries.  Process-wide. */
+ * reference): 0 = interpolation on the vector ALUs, 1 or 2 = as small matrix products on the matrix cores (the default;
+ * the environment variable SNWS_UPCONV_MFMA overrides it at first use).  The two families give the same products and
+ * differ only in the f32 summation order.  Returns the previous mode; any other argument only queries.  Process-wide. */
 int snws_upconv_fwd_mode(int mode);
 int snws_upconv_fwd_stats(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, int dtype, int N, int h,
                           int w, int C_out, int k, int ksize, float* stat_part, void* stream);

@@ -520,6 +520,87 @@ struct UpMfma {
   static constexpr int LDS_BYTES = MAIN_BYTES + 4 * 64 * 2 * 4;
 };
 
+// Epilogue shared by the matrix-core forwards: accumulators (+ bias) -> bf16 tile in LDS (lane holds pixel m of block
+// (i, j) and channels 16 cb + 4 g + (0..3)), then 8 lanes x 16 B = one pixel's 64 channels per store and the optional
+// per-channel partial moments of the rounded outputs minus the bias.  The caller has made sure nobody still reads the
+// tile's LDS; returns with every wave past its last read of st_lds' previous contents (one barrier inside).
+__device__ __forceinline__ void up_mfma_epilogue(const up_f32x4 (&acc)[2][2][4], const float (&b4)[4][4], const float (&sh)[8],
+                                                 unsigned char* out_lds, float* st_lds, bf16_t* __restrict__ y, int64_t ldy,
+                                                 float* __restrict__ stat, int n, int H, int W, int py0, int px0, int Co,
+                                                 int cchunk, int tilesX, int tx_) {
+  constexpr int OUT_RS = 144;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int c8 = tid & 7, pxl = tid >> 3;
+  const int ch = cchunk * 64 + c8 * 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int qp = (4 * i + (m >> 2)) * SEP_TW + 4 * (wave + 4 * jj) + (m & 3);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const up_f32x4 v = acc[i][jj][cb];
+        *reinterpret_cast<uint2*>(out_lds + qp * OUT_RS + (16 * cb + 4 * g) * 2) =
+            make_uint2(pack_bf16x2(v[0] + b4[cb][0], v[1] + b4[cb][1]), pack_bf16x2(v[2] + b4[cb][2], v[3] + b4[cb][3]));
+      }
+    }
+  __syncthreads();
+  const int px = px0 + pxl;
+  const bool col_ok = px < W;
+  float S[8], Q[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) S[v] = Q[v] = 0.f;
+#pragma unroll
+  for (int py = 0; py < SEP_TH; ++py) {
+    if (col_ok && py0 + py < H) {
+      const uint4 v = *reinterpret_cast<const uint4*>(out_lds + (py * SEP_TW + pxl) * OUT_RS + c8 * 16);
+      *reinterpret_cast<uint4*>(y + (((int64_t)n * H + py0 + py) * W + px) * ldy + ch) = v;
+      if (stat) {
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f0 = __uint_as_float(u[e] << 16) - sh[2 * e];
+          const float f1 = __uint_as_float(u[e] & 0xffff0000u) - sh[2 * e + 1];
+          S[2 * e] += f0; Q[2 * e] += f0 * f0;
+          S[2 * e + 1] += f1; Q[2 * e + 1] += f1 * f1;
+        }
+      }
+    }
+  }
+  if (stat) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        S[e] += __shfl_xor(S[e], o, 64);
+        Q[e] += __shfl_xor(Q[e], o, 64);
+      }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        st_lds[(wave * 64 + lane * 8 + e) * 2] = S[e];
+        st_lds[(wave * 64 + lane * 8 + e) * 2 + 1] = Q[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        s += st_lds[(wv * 64 + tid) * 2];
+        q += st_lds[(wv * 64 + tid) * 2 + 1];
+      }
+      const int64_t tile = (int64_t)blockIdx.y * tilesX + tx_;
+      const int64_t T = (int64_t)gridDim.y * tilesX;
+      float* o = stat + (((int64_t)n * T + tile) * Co + cchunk * 64 + tid) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
+  }
+}
+
 template <int K, int PH>
 __device__ __forceinline__ void upconv_mfma_body(const bf16_t* __restrict__ Z, int64_t ldz, bf16_t* __restrict__ y,
                                                  int64_t ldy, const float* __restrict__ bias, float* __restrict__ stat,
@@ -648,8 +729,7 @@ __device__ __forceinline__ void upconv_mfma_body(const bf16_t* __restrict__ Z, i
       }
 
   // epilogue mapping (as the kernel above): 8 lanes x 16 B = one pixel's 64 channels, a thread walks down the 8 rows
-  const int c8 = tid & 7, pxl = tid >> 3;
-  const int ch = cchunk * 64 + c8 * 8;
+  const int ch = cchunk * 64 + (tid & 7) * 8;
   unsigned char* out_lds = smem + M::OUT_OFF;
   float* st_lds = reinterpret_cast<float*>(smem + M::MAIN_BYTES);
   float b4[4][4];
@@ -773,79 +853,174 @@ __device__ __forceinline__ void upconv_mfma_body(const bf16_t* __restrict__ Z, i
       }
     }
 
-    // ---- accumulators (+ bias) -> bf16 tile in LDS: lane holds pixel m of block (i, j) and channels 16 cb + 4 g + (0..3)
-    // (two buffers: the tile has its own region, and the barrier at the top of this iteration ordered the previous
-    //  strip's readers before these writes; one buffer: the tile reuses it once every wave is done reading)
-    if (M::NBUF == 1) __syncthreads();
+    if (M::NBUF == 1) __syncthreads();                            // one buffer: the tile reuses it once every wave is done reading
+    up_mfma_epilogue(acc, b4, sh, out_lds, st_lds, y, ldy, stat, n, H, W, py0, px0, Co, cchunk, tilesX, tx_);
+  }
+}
+
+// ---- k = 2: four consecutive outputs of one tap touch up to 4 source pixels per axis, so the contraction is done per
+// tap column on v_mfma_f32_16x16x16_bf16: entry (source row r, source column c) = 4 r + c fills the 16 exactly, a lane
+// (pixel m, k quad g) holds the weights wy(r = g) * wx(tx; c = 0..3), and one transposing read (k rows = the four source
+// columns of row g) feeds the hi and the lo product.  Block rows 0..3 and 4..7 have the same phase, so one weight set
+// serves all four blocks of a wave; taps outside the image are zeroed per lane.  The three filter rows are staged one at
+// a time (43 KB each) and the epilogue tile reuses that buffer.
+__device__ __forceinline__ void upconv_mfma2_body(const bf16_t* __restrict__ Z, int64_t ldz, bf16_t* __restrict__ y,
+                                                  int64_t ldy, const float* __restrict__ bias, float* __restrict__ stat,
+                                                  int h, int w, int Co, int tilesX, int tilesPerWg, unsigned char* smem) {
+  constexpr int K = 2;
+  using G = UpStage<2, 0>;
+  constexpr int PIXB = G::QS * 16;
+  constexpr int OUT_BYTES = SEP_TH * SEP_TW * 144;
+  constexpr int MAIN = G::LDS_BYTES > OUT_BYTES ? G::LDS_BYTES : OUT_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunk = Co / 64;
+  const int cchunk = blockIdx.x % nchunk, xs = blockIdx.x / nchunk;
+  const int py0 = blockIdx.y * SEP_TH, n = blockIdx.z;
+  const int H = h * K, W = w * K;
+  const int base_lo = py0 / K + G::FLMIN;
+  const unsigned char* zimg = reinterpret_cast<const unsigned char*>(Z + (int64_t)n * h * w * ldz + cchunk * 64);
+  const int m = lane & 15, g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+
+  // weights: whi / wlo[ty][tx] = the four entries c = 0..3 of this lane's source row g, packed in pairs
+  int c0[3];
+  float wxc[3][4];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) {
+    const int q0 = 4 * wave + tx - 1;
+    c0[tx] = (2 * q0 - 1) >> 2;                                  // floor((q + 0.5) / 2 - 0.5) = (2 q - 1) >> 2
+    const int t2 = 2 * (q0 + (m & 3)) - 1;
+    const int d = (t2 >> 2) - c0[tx];
+    const float lam = (float)(t2 & 3) * 0.25f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wxc[tx][c] = c == d ? 1.f - lam : (c == d + 1 ? lam : 0.f);
+  }
+  unsigned whi[3][3][2], wlo[3][3][2];
+#pragma unroll
+  for (int ty = 0; ty < 3; ++ty) {
+    const int q0 = ty - 1;                                        // (block row 4 i has the same phase)
+    const int t2 = 2 * (q0 + (m >> 2)) - 1;
+    const int d = (t2 >> 2) - ((2 * q0 - 1) >> 2);
+    const float lam = (float)(t2 & 3) * 0.25f;
+    const float wy = g == d ? 1.f - lam : (g == d + 1 ? lam : 0.f);
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        unsigned hi2[2], lo2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float wv = wy * wxc[tx][2 * e2 + u];            // a multiple of 1/16: exact in bf16 (lo is zero; kept for symmetry)
+          const unsigned hb = __float_as_uint(wv) & 0xffff0000u;
+          hi2[u] = hb >> 16;
+          lo2[u] = __float_as_uint(wv - __uint_as_float(hb)) >> 16;
+        }
+        whi[ty][tx][e2] = hi2[0] | (hi2[1] << 16);
+        wlo[ty][tx][e2] = lo2[0] | (lo2[1] << 16);
+      }
+  }
+  (void)wlo;
+
+  unsigned char* out_lds = smem;
+  float* st_lds = reinterpret_cast<float*>(smem + MAIN);
+  float b4[4][4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b4[cb][e] = bias ? bias[cchunk * 64 + 16 * cb + 4 * g + e] : 0.f;
+  const int ch = cchunk * 64 + (tid & 7) * 8;
+  float sh[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) sh[v] = (stat && bias) ? bias[ch + v] : 0.f;
+  const bool yedge = py0 == 0 || py0 + SEP_TH >= H;               // block-uniform
+
+  const int t_begin = xs * tilesPerWg;
+  const int t_end = t_begin + tilesPerWg < tilesX ? t_begin + tilesPerWg : tilesX;
+  for (int tx_ = t_begin; tx_ < t_end; ++tx_) {
+    const int px0 = tx_ * SEP_TW;
+    const int col_lo = px0 / K - 1;
+    unsigned src[G::JN];
+#pragma unroll
+    for (int j = 0; j < G::JN; ++j) {
+      const int s = (wave + 4 * j) * 64 + lane;
+      const int q = s / G::QS, c = s - q * G::QS;
+      const int qr = q / G::CW, qc = q - qr * G::CW;
+      int row = base_lo + qr, col = col_lo + qc;
+      row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
+      col = col < 0 ? 0 : (col > w - 1 ? w - 1 : col);
+      const int tx = c >> 3, jc = c & 7;
+      const bool real = s < G::NS && c < 24;
+      src[j] = real ? (unsigned)((((int64_t)row * w + col) * ldz + (int64_t)tx * Co + jc * 8) * 2) : 0u;
+    }
+    const bool edge = yedge || px0 == 0 || px0 + SEP_TW >= W;     // block-uniform: some taps fall outside the image
+    // staged column of this lane's transposing-read row (source column c = tq) per (jj, tx), as a byte offset
+    int acol[2][3];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        int col = c0[tx] + 8 * jj + 1 + tq;
+        col = col > G::CW - 1 ? G::CW - 1 : col;                  // (only entries with a zero weight get clamped)
+        acol[jj][tx] = col * PIXB + tx * 128 + tp * 8;
+      }
+
+    up_f32x4 acc[2][2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int qp = (4 * i + (m >> 2)) * SEP_TW + 4 * (wave + 4 * jj) + (m & 3);
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          const up_f32x4 v = acc[i][jj][cb];
-          *reinterpret_cast<uint2*>(out_lds + qp * M::OUT_RS + (16 * cb + 4 * g) * 2) =
-              make_uint2(pack_bf16x2(v[0] + b4[cb][0], v[1] + b4[cb][1]), pack_bf16x2(v[2] + b4[cb][2], v[3] + b4[cb][3]));
-        }
-      }
-    __syncthreads();
+        for (int cb = 0; cb < 4; ++cb) acc[i][jj][cb] = up_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- stores (8 lanes x 16 B = one pixel's 64 channels) and the optional per-channel partial moments
-    const int px = px0 + pxl;
-    const bool col_ok = px < W;
-    float S[8], Q[8];
 #pragma unroll
-    for (int v = 0; v < 8; ++v) S[v] = Q[v] = 0.f;
+    for (int ty = 0; ty < 3; ++ty) {
+      __syncthreads();                                            // every wave is done with the previous stage / strip
+      const unsigned char* zt = zimg + (int64_t)ty * 3 * Co * 2;
 #pragma unroll
-    for (int py = 0; py < SEP_TH; ++py) {
-      if (col_ok && py0 + py < H) {
-        const uint4 v = *reinterpret_cast<const uint4*>(out_lds + (py * SEP_TW + pxl) * M::OUT_RS + c8 * 16);
-        *reinterpret_cast<uint4*>(y + (((int64_t)n * H + py0 + py) * W + px) * ldy + ch) = v;
-        if (stat) {
-          const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float f0 = __uint_as_float(u[e] << 16) - sh[2 * e];
-            const float f1 = __uint_as_float(u[e] & 0xffff0000u) - sh[2 * e + 1];
-            S[2 * e] += f0; Q[2 * e] += f0 * f0;
-            S[2 * e + 1] += f1; Q[2 * e + 1] += f1 * f1;
-          }
-        }
-      }
-    }
-    if (stat) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
-          S[e] += __shfl_xor(S[e], o, 64);
-          Q[e] += __shfl_xor(Q[e], o, 64);
-        }
-      }
-      if (lane < 8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          st_lds[(wave * 64 + lane * 8 + e) * 2] = S[e];
-          st_lds[(wave * 64 + lane * 8 + e) * 2 + 1] = Q[e];
-        }
-      }
+      for (int j = 0; j < G::JN; ++j)
+        if (wave + 4 * j < G::NI) up_glds16(zt + src[j], smem + (wave + 4 * j) * 1024);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid < 64) {
-        float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-          s += st_lds[(wv * 64 + tid) * 2];
-          q += st_lds[(wv * 64 + tid) * 2 + 1];
-        }
-        const int64_t tile = (int64_t)blockIdx.y * tilesX + tx_;
-        const int64_t T = (int64_t)gridDim.y * tilesX;
-        float* o = stat + (((int64_t)n * T + tile) * Co + cchunk * 64 + tid) * 2;
-        o[0] = s;
-        o[1] = q;
+      for (int i = 0; i < 2; ++i) {
+        constexpr int dummy = 0; (void)dummy;
+        int rr = up_fl<2>(4 * i + ty - 1) - G::FLMIN + g;         // staged row of this lane's contraction row
+        rr = rr > G::R - 1 ? G::R - 1 : rr;                       // (only entries with a zero weight get clamped)
+        const int rowb = rr * (G::CW * PIXB);
+        const int qy = py0 + 4 * i + (m >> 2) + ty - 1;
+        const bool rowok = qy >= 0 && qy < H;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            unsigned h2[2] = {whi[ty][tx][0], whi[ty][tx][1]};
+            if (edge) {
+              const int qx = px0 + 16 * jj + 4 * wave + (m & 3) + tx - 1;
+              const bool ok = rowok && qx >= 0 && qx < W;
+              h2[0] = ok ? h2[0] : 0u;
+              h2[1] = ok ? h2[1] : 0u;
+            }
+            up_short4 wh;
+            wh[0] = (short)(h2[0] & 0xffff); wh[1] = (short)(h2[0] >> 16); wh[2] = (short)(h2[1] & 0xffff); wh[3] = (short)(h2[1] >> 16);
+            const unsigned char* p0 = smem + rowb + acol[jj][tx];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+              const up_short4 zf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) up_short4*)(p0 + cb * 32));
+              acc[i][jj][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(zf, wh, acc[i][jj][cb], 0, 0, 0);
+            }
+          }
       }
     }
+    __syncthreads();                                              // the tile reuses the stage buffer
+    up_mfma_epilogue(acc, b4, sh, out_lds, st_lds, y, ldy, stat, n, H, W, py0, px0, Co, cchunk, tilesX, tx_);
   }
+}
+
+__global__ __launch_bounds__(256, 2) void upconv_fwd_mfma2_kernel(const bf16_t* __restrict__ Z, int64_t ldz,
+                                                                 bf16_t* __restrict__ y, int64_t ldy,
+                                                                 const float* __restrict__ bias, float* __restrict__ stat,
+                                                                 int h, int w, int Co, int tilesX, int tilesPerWg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char up_smem[];
+  upconv_mfma2_body(Z, ldz, y, ldy, bias, stat, h, w, Co, tilesX, tilesPerWg, up_smem);
 }
 
 template <int K>
@@ -865,11 +1040,14 @@ __global__ __launch_bounds__(256, 2) void upconv_fwd_mfma_kernel(const bf16_t* _
 template <int K>
 int launch_fwd_mfma_k(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, float* stat, int N, int h, int w,
                       int Co, hipStream_t st) {
-  constexpr int LDS = UpMfma<K>::LDS_BYTES;
+  constexpr int OUTB = SEP_TH * SEP_TW * 144;
+  constexpr int LDS2 = (UpStage<2, 0>::LDS_BYTES > OUTB ? UpStage<2, 0>::LDS_BYTES : OUTB) + 4 * 64 * 2 * 4;
+  constexpr int LDS = K == 2 ? LDS2 : UpMfma<K>::LDS_BYTES;
   static PerDeviceOnce once;
   std::atomic<bool>* const attr_set = once.flag();
   if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_fwd_mfma_kernel<K>),
+    hipError_t e = hipFuncSetAttribute(K == 2 ? reinterpret_cast<const void*>(&upconv_fwd_mfma2_kernel)
+                                              : reinterpret_cast<const void*>(&upconv_fwd_mfma_kernel<K>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       snws_set_error("upconv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -887,7 +1065,10 @@ int launch_fwd_mfma_k(const void* Z, int64_t ldz, void* y, int64_t ldy, const fl
   const int tilesPerWg = cdiv(tilesX, xsplits);
   xsplits = cdiv(tilesX, tilesPerWg);
   dim3 grid((unsigned)((Co / 64) * xsplits), (unsigned)tilesY, (unsigned)N);
-  upconv_fwd_mfma_kernel<K><<<grid, 256, LDS, st>>>((const bf16_t*)Z, ldz, (bf16_t*)y, ldy, bias, stat, h, w, Co, tilesX, tilesPerWg);
+  if (K == 2)
+    upconv_fwd_mfma2_kernel<<<grid, 256, LDS, st>>>((const bf16_t*)Z, ldz, (bf16_t*)y, ldy, bias, stat, h, w, Co, tilesX, tilesPerWg);
+  else
+    upconv_fwd_mfma_kernel<K><<<grid, 256, LDS, st>>>((const bf16_t*)Z, ldz, (bf16_t*)y, ldy, bias, stat, h, w, Co, tilesX, tilesPerWg);
   return SNWS_OK;
 }
 
@@ -901,9 +1082,8 @@ int launch_fwd_mfma(const void* Z, int64_t ldz, void* y, int64_t ldy, const floa
   }
 }
 
-// The matrix form wins for k >= 4 (139 / 169 / 243 us against 194 / 238 / 344 us per launch for k = 4 / 8 / 16 on the
-// decoder's shapes); for k = 2 a 4-pixel run touches 4 source pixels per axis, the contraction doubles and the VALU form
-// stays ahead.  SNWS_UPCONV_MFMA=0 / 2 force the VALU / the matrix form for every k (A/B measurements).
+// The matrix forms win for every k on the decoder's shapes: 155 / 134 / 163 / 197 us against 197 / 194 / 238 / 344 us per
+// launch for k = 2 / 4 / 8 / 16.  SNWS_UPCONV_MFMA=0 (or snws_upconv_fwd_mode(0)) selects the vector-ALU form.
 std::atomic<int> g_upconv_mode{-1};
 bool upconv_mfma_on(int k) {
   int mode = g_upconv_mode.load(std::memory_order_relaxed);
@@ -911,7 +1091,8 @@ bool upconv_mfma_on(int k) {
     mode = getenv("SNWS_UPCONV_MFMA") ? atoi(getenv("SNWS_UPCONV_MFMA")) : 1;
     g_upconv_mode.store(mode, std::memory_order_relaxed);
   }
-  return mode == 2 || (mode == 1 && k >= 4);
+  (void)k;
+  return mode != 0;
 }
 
 // Backward: one thread per (source pixel, channel group) for ALL taps: every dy value of the (2k+2)^2 window is
