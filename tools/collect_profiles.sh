@@ -17,3 +17,6 @@ timeout -k 10 200 python bench.py --no-cpu-baseline --model unet3p_res_ocr > $ou
 timeout -k 10 200 python bench.py --no-cpu-baseline --dtype f32 > $out/bench_f32_gpus1.json 2> $out/bench_f32.err
 cp $out/kstats/bench_kernel_stats.csv $out/bench_bs16_512_kernel_stats.csv
 cut -c1-200 $out/bench_gpus1.json $out/bench_res_ocr_gpus1.json $out/bench_f32_gpus1.json
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kstats_ocr -o bench -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-events --model unet3p_res_ocr > $out/kstats_ocr.log 2>&1
+cp $out/kstats_ocr/bench_kernel_stats.csv $out/res_ocr_bs16_512_kernel_stats.csv
