@@ -392,6 +392,9 @@ int snws_upconv_stat_tiles(int H, int W);
  * the environment variable SNWS_UPCONV_MFMA overrides it at first use).  The two families give the same products and
  * differ only in the f32 summation order.  Returns the previous mode; any other argument only queries.  Process-wide. */
 int snws_upconv_fwd_mode(int mode);
+/* The same switch for snws_upconv_bwd with k = 2 (bf16, 3x3, C_out a multiple of 64): 1 (default; SNWS_UPCONV_BWD_MFMA
+ * overrides it at first use) = matrix cores, 0 = the separable vector-ALU kernel. */
+int snws_upconv_bwd_mode(int mode);
 int snws_upconv_fwd_stats(const void* Z, int64_t ldz, void* y, int64_t ldy, const float* bias, int dtype, int N, int h,
                           int w, int C_out, int k, int ksize, float* stat_part, void* stream);
 

@@ -19,6 +19,8 @@
 
 namespace {
 
+__device__ __attribute__((aligned(256))) unsigned int up_zero_page[64];   // never written: all zero
+
 __device__ __forceinline__ void up_tap(int o, int k, int in, int& i0, int& i1, float& lam) {
   float src = ((float)o + 0.5f) / (float)k - 0.5f;
   src = src < 0.f ? 0.f : src;
@@ -1279,6 +1281,283 @@ __global__ __launch_bounds__(256) void upconv_bwd_sep_kernel(const bf16_t* __res
   }
 }
 
+// ---- backward for k = 2 on the matrix cores (bf16, 3x3, 64-channel chunks).
+// dZ_t(s) = sum_q w(q -> s) dy(q - t + 1): for a 4x4 block of source pixels the positions q with a non-zero weight form a
+// 10x10 window, the same for every tap - only the dy pixel read for a position shifts with the tap.  Per tap that is
+//   D[64 channels][16 source pixels] = dyrows[64][160] * Wt[160][16],   contraction entry = (window row, window column
+//   padded to 16), read with the transposing LDS read at (row - ty, column - tx) of the staged dy window,
+// with ONE weight matrix (products of two interpolation weights: multiples of 1/16, exact in bf16) held in registers.
+// The weights come from tap_weight(), i.e. with the interpolation's border clamp and the convolution's zero padding, so
+// border blocks need no special path.  A workgroup stages the 12x36 dy window of a 4x16 source tile (8x32 outputs + 2),
+// wave w owns source columns 4w..4w+3; 144-byte pixel stride keeps the transposing reads conflict-free; a tap's result
+// leaves through a wave-private 16x64 scratch as whole 128-byte lines.  45 matrix instructions per tap and wave replace
+// ~66 VALU operations per output element of the separable kernel below.
+struct UpB2 {
+  static constexpr int TR = 12, TC = 36;
+  static constexpr int SL = 9, PIXB = SL * 16;
+  static constexpr int NS = TR * TC * SL, NI = (NS + 63) / 64, JN = (NI + 3) / 4;
+  static constexpr int STAGE_BYTES = NI * 1024;
+  static constexpr int SCR_RS = 144, SCR = 16 * SCR_RS;
+  static constexpr int LDS_BYTES = STAGE_BYTES + 4 * SCR;
+  static constexpr int KS = 5;
+};
+
+__global__ __launch_bounds__(256, 2) void upconv_bwd_mfma2_kernel(const bf16_t* __restrict__ dy, int64_t lddy,
+                                                                 bf16_t* __restrict__ dZ, int64_t lddz, int h, int w,
+                                                                 int Co, int tilesX, int tilesPerWg) {
+  using G = UpB2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunk = Co / 64;
+  const int cchunk = blockIdx.x % nchunk, xs = blockIdx.x / nchunk;
+  const int sy0 = blockIdx.y * 4, n = blockIdx.z;
+  const int H = 2 * h, W = 2 * w;
+  const int m = lane & 15, g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int sr = m >> 2, sc = m & 3;
+  unsigned char* scr = smem + G::STAGE_BYTES + wave * G::SCR;
+  const unsigned char* dimg = reinterpret_cast<const unsigned char*>(dy + (int64_t)n * H * W * lddy + cchunk * 64);
+
+  // row weights of this lane's source row for the window rows 2 ks + (g >> 1)
+  float wyv[G::KS];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) wyv[ks] = tap_weight(2 * sy0 - 1 + 2 * ks + (g >> 1), H, 0.5f, h, sy0 + sr);
+  // transposing-read rows of the dy operand: contraction entry 32 ks + 8 g + 4 hq + tq = (window row 2 ks + (g >> 1),
+  // window column 8 (g & 1) + 4 hq + tq; padding columns >= 10 carry zero weights and read a real pixel)
+  int abase[2];
+#pragma unroll
+  for (int hq = 0; hq < 2; ++hq) {
+    int qc = 8 * (g & 1) + 4 * hq + tq;
+    qc = qc > 9 ? 9 : qc;
+    abase[hq] = (((g >> 1) + 2) * G::TC + 8 * wave + qc + 2) * G::PIXB + tp * 8;
+  }
+
+  const int t_begin = xs * tilesPerWg;
+  const int t_end = t_begin + tilesPerWg < tilesX ? t_begin + tilesPerWg : tilesX;
+  for (int tx_ = t_begin; tx_ < t_end; ++tx_) {
+    const int sx0 = tx_ * 16, sxb = sx0 + 4 * wave;
+    __syncthreads();                                              // every wave is done reading the previous window
+#pragma unroll
+    for (int j = 0; j < G::JN; ++j) {
+      const int piece = wave + 4 * j;
+      if (piece < G::NI) {
+        const int s = piece * 64 + lane;
+        const int pix = s / G::SL, slot = s - pix * G::SL;
+        const int r = pix / G::TC, c = pix - r * G::TC;
+        const int py = 2 * sy0 - 2 + r, px = 2 * sx0 - 2 + c;
+        const bool ok = s < G::NS && slot < 8 && py >= 0 && py < H && px >= 0 && px < W;
+        const void* src = ok ? (const void*)(dimg + (((int64_t)py * W + px) * lddy + slot * 8) * 2) : (const void*)up_zero_page;
+        up_glds16(src, smem + piece * 1024);
+      }
+    }
+    // column weights of this lane's source column for the window columns 8 (g & 1) + e, and the packed products
+    unsigned wf[G::KS][4];
+    {
+      float wxv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int qc = 8 * (g & 1) + e;
+        wxv[e] = qc < 10 ? tap_weight(2 * sxb - 1 + qc, W, 0.5f, w, sxb + sc) : 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)      // multiples of 1/16 (sums of them at a clamped border): exact in bf16
+          wf[ks][e2] = (__float_as_uint(wyv[ks] * wxv[2 * e2]) >> 16) | (__float_as_uint(wyv[ks] * wxv[2 * e2 + 1]) & 0xffff0000u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ty = tap / 3, tx = tap % 3;
+      const int toff = -(ty * G::TC + tx) * G::PIXB;
+      up_f32x4 acc[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = up_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const up_bf16x8 wv = __builtin_bit_cast(up_bf16x8, make_uint4(wf[ks][0], wf[ks][1], wf[ks][2], wf[ks][3]));
+        const unsigned char* p0 = smem + abase[0] + ks * (2 * G::TC * G::PIXB) + toff;
+        const unsigned char* p1 = smem + abase[1] + ks * (2 * G::TC * G::PIXB) + toff;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(up_tr_frag(p0 + cb * 32, p1 + cb * 32), wv, acc[cb], 0, 0, 0);
+      }
+      // D[channel 16 cb + 4 g + j][source pixel m] -> scratch -> one 128-byte line per (source pixel, tap)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        *reinterpret_cast<uint2*>(scr + m * G::SCR_RS + (16 * cb + 4 * g) * 2) =
+            make_uint2(pack_bf16x2(acc[cb][0], acc[cb][1]), pack_bf16x2(acc[cb][2], acc[cb][3]));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int q = it * 64 + lane, p16 = q >> 3, c8 = q & 7;
+        const int sy = sy0 + (p16 >> 2), sx = sxb + (p16 & 3);
+        if (sy < h && sx < w)
+          *reinterpret_cast<uint4*>(dZ + (((int64_t)n * h + sy) * w + sx) * lddz + (int64_t)tap * Co + cchunk * 64 + c8 * 8) =
+              *reinterpret_cast<const uint4*>(scr + p16 * G::SCR_RS + c8 * 16);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
+// ---- the same for k = 4: a 4x4 source block sees a 20x20 window of positions (contraction = 20 window rows x 32
+// columns, 20 used), its dy window is 22x22 pixels (70 KB staged), so a workgroup owns ONE block and its four waves split
+// the 64 channels; weights are multiples of 1/64 (exact in bf16).  A wave stores its 16 channels of a (pixel, tap) line
+// as 32-byte segments; the four waves of the workgroup complete the 128-byte lines within the same tap.
+struct UpB4 {
+  static constexpr int TR = 22, TC = 22;
+  static constexpr int SL = 9, PIXB = SL * 16;
+  static constexpr int NS = TR * TC * SL, NI = (NS + 63) / 64, JN = (NI + 3) / 4;
+  static constexpr int LDS_BYTES = NI * 1024;
+  static constexpr int KS = 20;
+};
+
+__global__ __launch_bounds__(256, 2) void upconv_bwd_mfma4_kernel(const bf16_t* __restrict__ dy, int64_t lddy,
+                                                                 bf16_t* __restrict__ dZ, int64_t lddz, int h, int w,
+                                                                 int Co, int tilesX, int tilesPerWg) {
+  using G = UpB4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunk = Co / 64;
+  const int cchunk = blockIdx.x % nchunk, xs = blockIdx.x / nchunk;
+  const int sy0 = blockIdx.y * 4, n = blockIdx.z;
+  const int H = 4 * h, W = 4 * w;
+  const int m = lane & 15, g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int sr = m >> 2, sc = m & 3;
+  const unsigned char* dimg = reinterpret_cast<const unsigned char*>(dy + (int64_t)n * H * W * lddy + cchunk * 64);
+
+  // row weights of this lane's source row for the 20 window rows (k-step ks = window row ks)
+  float wyv[G::KS];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) wyv[ks] = tap_weight(4 * sy0 - 2 + ks, H, 0.25f, h, sy0 + sr);
+  // transposing-read rows of the dy operand: entry 32 ks + 8 g + 4 hq + tq = (window row ks, window column 8 g + 4 hq + tq)
+  int abase[2];
+#pragma unroll
+  for (int hq = 0; hq < 2; ++hq) {
+    int qc = 8 * g + 4 * hq + tq;
+    qc = qc > 19 ? 19 : qc;                   // padding columns carry zero weights and read a real pixel
+    abase[hq] = (2 * G::TC + qc + 2) * G::PIXB + wave * 32 + tp * 8;
+  }
+
+  const int t_begin = xs * tilesPerWg;
+  const int t_end = t_begin + tilesPerWg < tilesX ? t_begin + tilesPerWg : tilesX;
+  for (int tx_ = t_begin; tx_ < t_end; ++tx_) {
+    const int sx0 = tx_ * 4;
+    __syncthreads();                                              // every wave is done reading the previous window
+#pragma unroll
+    for (int j = 0; j < G::JN; ++j) {
+      const int piece = wave + 4 * j;
+      if (piece < G::NI) {
+        const int s = piece * 64 + lane;
+        const int pix = s / G::SL, slot = s - pix * G::SL;
+        const int r = pix / G::TC, c = pix - r * G::TC;
+        const int py = 4 * sy0 - 3 + r, px = 4 * sx0 - 3 + c;
+        const bool ok = s < G::NS && slot < 8 && py >= 0 && py < H && px >= 0 && px < W;
+        const void* src = ok ? (const void*)(dimg + (((int64_t)py * W + px) * lddy + slot * 8) * 2) : (const void*)up_zero_page;
+        up_glds16(src, smem + piece * 1024);
+      }
+    }
+    float wxv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int qc = 8 * g + e;
+      wxv[e] = qc < 20 ? tap_weight(4 * sx0 - 2 + qc, W, 0.25f, w, sx0 + sc) : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int sy = sy0 + sr, sx = sx0 + sc;
+    bf16_t* op = dZ + (((int64_t)n * h + sy) * w + sx) * lddz + cchunk * 64 + 16 * wave + 4 * g;
+    const bool pix_ok = sy < h && sx < w;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ty = tap / 3, tx = tap % 3;
+      const int toff = -(ty * G::TC + tx) * G::PIXB;
+      up_f32x4 acc = up_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        unsigned wf[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)        // multiples of 1/64 (sums of them at a clamped border): exact in bf16
+          wf[e2] = (__float_as_uint(wyv[ks] * wxv[2 * e2]) >> 16) | (__float_as_uint(wyv[ks] * wxv[2 * e2 + 1]) & 0xffff0000u);
+        const up_bf16x8 wv = __builtin_bit_cast(up_bf16x8, make_uint4(wf[0], wf[1], wf[2], wf[3]));
+        const unsigned char* p0 = smem + abase[0] + ks * (G::TC * G::PIXB) + toff;
+        const unsigned char* p1 = smem + abase[1] + ks * (G::TC * G::PIXB) + toff;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(up_tr_frag(p0, p1), wv, acc, 0, 0, 0);
+      }
+      // D[channel 16 wave + 4 g + j][source pixel m]
+      if (pix_ok)
+        *reinterpret_cast<uint2*>(op + (int64_t)tap * Co) = make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
+    }
+  }
+}
+
+int launch_bwd_mfma4(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int N, int h, int w, int Co, hipStream_t st) {
+  using G = UpB4;
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_bwd_mfma4_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      snws_set_error("upconv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    if (attr_set) attr_set->store(true, std::memory_order_release);
+  }
+  const int tilesX = cdiv(w, 4), tilesY = cdiv(h, 4);
+  const int64_t rows = (int64_t)(Co / 64) * tilesY * N;
+  int xsplits = (int)cdiv64(2048, rows);
+  if (xsplits > tilesX) xsplits = tilesX;
+  if (xsplits < 1) xsplits = 1;
+  const int tilesPerWg = cdiv(tilesX, xsplits);
+  xsplits = cdiv(tilesX, tilesPerWg);
+  dim3 grid((unsigned)((Co / 64) * xsplits), (unsigned)tilesY, (unsigned)N);
+  upconv_bwd_mfma4_kernel<<<grid, 256, G::LDS_BYTES, st>>>((const bf16_t*)dy, lddy, (bf16_t*)dZ, lddz, h, w, Co, tilesX, tilesPerWg);
+  return SNWS_OK;
+}
+
+int launch_bwd_mfma2(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int N, int h, int w, int Co, hipStream_t st) {
+  using G = UpB2;
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_bwd_mfma2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      snws_set_error("upconv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    if (attr_set) attr_set->store(true, std::memory_order_release);
+  }
+  const int tilesX = cdiv(w, 16), tilesY = cdiv(h, 4);
+  const int64_t rows = (int64_t)(Co / 64) * tilesY * N;
+  int xsplits = (int)cdiv64(2048, rows);
+  if (xsplits > tilesX) xsplits = tilesX;
+  if (xsplits < 1) xsplits = 1;
+  const int tilesPerWg = cdiv(tilesX, xsplits);
+  xsplits = cdiv(tilesX, tilesPerWg);
+  dim3 grid((unsigned)((Co / 64) * xsplits), (unsigned)tilesY, (unsigned)N);
+  upconv_bwd_mfma2_kernel<<<grid, 256, G::LDS_BYTES, st>>>((const bf16_t*)dy, lddy, (bf16_t*)dZ, lddz, h, w, Co, tilesX, tilesPerWg);
+  return SNWS_OK;
+}
+
+std::atomic<int> g_upconv_bwd_mode{-1};
+bool upconv_bwd_mfma_on() {
+  int mode = g_upconv_bwd_mode.load(std::memory_order_relaxed);
+  if (mode < 0) {
+    mode = getenv("SNWS_UPCONV_BWD_MFMA") ? atoi(getenv("SNWS_UPCONV_BWD_MFMA")) : 1;
+    g_upconv_bwd_mode.store(mode, std::memory_order_relaxed);
+  }
+  return mode != 0;
+}
+
 template <int K, int PARTS>
 void launch_bwd_sep(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int N, int h, int w, int Co, hipStream_t st) {
   const int64_t total = (int64_t)N * h * w * (Co / 8) * PARTS;
@@ -1341,6 +1620,13 @@ extern "C" int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy,
   return SNWS_OK;
 }
 
+extern "C" int snws_upconv_bwd_mode(int mode) {
+  upconv_bwd_mfma_on();                 // (reads the environment on first use)
+  const int prev = g_upconv_bwd_mode.load(std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 1) g_upconv_bwd_mode.store(mode, std::memory_order_relaxed);
+  return prev;
+}
+
 extern "C" int snws_upconv_fwd_mode(int mode) {
   upconv_mfma_on(2);                    // (reads the environment on first use)
   const int prev = g_upconv_mode.load(std::memory_order_relaxed);
@@ -1373,6 +1659,12 @@ extern "C" int snws_upconv_bwd(const void* dy, int64_t lddy, void* dZ, int64_t l
   static const bool no_sep_bwd = getenv("SNWS_UPCONV_BWD_GATHER") != nullptr;   // A/B switch: the non-separable kernel
   if (!no_sep_bwd && dtype == SNWS_BF16 && ksize == 3 && C_out % 8 == 0 && lddz % 8 == 0 && lddy % 8 == 0 && al16(dZ) &&
       al16(dy) && (k == 2 || k == 4 || k == 8 || k == 16) && cdiv64(items * (C_out / 8) * 8, 256) < (1ll << 31)) {
+    if ((k == 2 || k == 4) && C_out % 64 == 0 && upconv_bwd_mfma_on() && N <= 65535 && cdiv(h, 4) <= 65535) {
+      if (int rc = k == 2 ? launch_bwd_mfma2(dy, lddy, dZ, lddz, N, h, w, C_out, st)
+                          : launch_bwd_mfma4(dy, lddy, dZ, lddz, N, h, w, C_out, st)) return rc;
+      SNWS_LAUNCH_CHECK("snws_upconv_bwd");
+      return SNWS_OK;
+    }
     switch (k) {
       case 2: launch_bwd_sep<2, 1>(dy, lddy, dZ, lddz, N, h, w, C_out, st); break;
       case 4: launch_bwd_sep<4, 2>(dy, lddy, dZ, lddz, N, h, w, C_out, st); break;

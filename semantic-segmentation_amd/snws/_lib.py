@@ -94,6 +94,7 @@ _SIGNATURES = {
     "snws_upconv_fwd": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_upconv_stat_tiles": (c_int, [c_int, c_int]),
     "snws_upconv_fwd_mode": (c_int, [c_int]),
+    "snws_upconv_bwd_mode": (c_int, [c_int]),
     "snws_upconv_fwd_stats": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "snws_upconv_bwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_resample_fwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -123,7 +124,7 @@ _SIGNATURES = {
 # entry points that return a status code (the others return a value)
 _STATUS = {k for k, (res, _) in _SIGNATURES.items() if res is c_int} - {
     "snws_version", "snws_conv_out_size", "snws_conv_mfma_tiles", "snws_sn_stats_tiles", "snws_ce_blocks",
-    "snws_upconv_stat_tiles", "snws_upconv_fwd_mode", "snws_tile_minmax_blocks", "snws_conv_f32_tiles", "snws_sn_head_tiles", "snws_gemm1x1_supported", "snws_ocr_tiles"}
+    "snws_upconv_stat_tiles", "snws_upconv_fwd_mode", "snws_upconv_bwd_mode", "snws_tile_minmax_blocks", "snws_conv_f32_tiles", "snws_sn_head_tiles", "snws_gemm1x1_supported", "snws_ocr_tiles"}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1630,6 +1630,47 @@ def test_upconv_matrix_form_matches_vector_form():
 
 
 @pytest.mark.gpu
+def test_upconv_backward_matrix_form_matches_vector_form():
+    """snws_upconv_bwd for k = 2 and 4 as matrix products (snws_upconv_bwd_mode 1) against the separable vector-ALU kernel
+    (mode 0): the same exact products (bf16 gradient x weights that are multiples of 1/16 or 1/64), another f32 summation order,
+    one bf16 rounding.  Sources that are not multiples of the 4x16 tile, one-pixel and one-row sources, 128 channels, a
+    strided dZ whose padding must stay untouched; and a constant gradient, for which interior entries are exact."""
+    from snws import _lib as L
+    lib = L.lib()
+    prev = lib.snws_upconv_bwd_mode(-1)
+    try:
+        torch.manual_seed(8)
+        for k, h, w, Co, pad in ((2, 20, 37, 64, 8), (2, 1, 1, 64, 0), (2, 3, 5, 64, 0), (2, 1, 40, 128, 0), (2, 9, 16, 64, 16),
+                                 (2, 4, 17, 64, 0), (4, 9, 17, 128, 8), (4, 1, 1, 64, 0), (4, 3, 2, 64, 0), (4, 1, 7, 64, 0),
+                                 (4, 8, 8, 64, 0), (4, 5, 13, 64, 16)):
+            N = 2
+            dy = torch.randn(N, h * k, w * k, Co, device=DEV).to(torch.bfloat16)
+            outs = []
+            for mode in (0, 1):
+                lib.snws_upconv_bwd_mode(mode)
+                dZ = torch.full((N, h, w, 9 * Co + pad), 7.0, device=DEV, dtype=torch.bfloat16)
+                L.call("snws_upconv_bwd", dy.data_ptr(), Co, dZ.data_ptr(), 9 * Co + pad, 1, N, h, w, Co, k, 3, 0)
+                if pad:
+                    assert float((dZ[..., 9 * Co:].float() - 7.0).abs().max()) == 0.0
+                outs.append(dZ[..., :9 * Co].float())
+            assert torch.isfinite(outs[1]).all()
+            diff = (outs[0] - outs[1]).abs()
+            assert float(diff.max()) <= 2 ** -7 * float(outs[0].abs().max()), (h, w, Co, float(diff.max()))
+            assert float((diff > 0).float().mean()) < 0.05, (h, w, Co)
+        # constant gradient: every interior source pixel receives k*k output pixels' worth per tap
+        h = w = 8
+        for k in (2, 4):
+            dy = torch.ones(1, k * h, k * w, 64, device=DEV, dtype=torch.bfloat16)
+            for mode in (0, 1):
+                lib.snws_upconv_bwd_mode(mode)
+                dZ = torch.empty(1, h, w, 9 * 64, device=DEV, dtype=torch.bfloat16)
+                L.call("snws_upconv_bwd", dy.data_ptr(), 64, dZ.data_ptr(), 9 * 64, 1, 1, h, w, 64, k, 3, 0)
+                assert float((dZ[:, 2:-2, 2:-2].float() - float(k * k)).abs().max()) == 0.0, (k, mode)
+    finally:
+        lib.snws_upconv_bwd_mode(prev)
+
+
+@pytest.mark.gpu
 def test_upconv_separable_backward_matches_gather_backward():
     """The separable backward (bf16, 3x3; window columns split over 1/2/4/8 lanes for k = 2/4/8/16) against the
     per-source-pixel gather kernel (SNWS_UPCONV_BWD_GATHER=1, read once per process, hence the child process): the
