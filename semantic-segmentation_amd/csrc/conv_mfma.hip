@@ -1037,6 +1037,141 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1w_kernel(Wgrad1wArgs a) {
   }
 }
 
+// 1x1 wgrad for filters with a multiple of 192 output channels - the tap form of conv(upsample(x)), 9 x 64 = 576 outputs
+// (modeling/UNet3p_SNws.py:131-155 of the reference) from 320 or 1024 inputs: a 192 x 160 (out, in) channel tile per
+// workgroup divides 576 x 320 without padding (the 128 x 128 tile above wastes a quarter of its work there, the 64 x 64
+// one re-reads the pixels for 45 tile pairs instead of 6).  Wave (wo, wi) owns 96 x 80 = 6 x 5 blocks of 16 x 16 on
+// v_mfma_f32_16x16x32_bf16: 11 fragment reads per 30 matrix instructions.  Pixels are one linear axis, 96 per tile
+// (three 32-pixel k-steps); LDS image per operand [96 px][channels] bf16, dy rows padded from 384 to 400 bytes so the
+// four pixel rows of a transposing read fall into different bank windows (x rows, 320 bytes, already do).
+struct Wgrad1tGeom {
+  static constexpr int TM = 192, TN = 160, TP = 96;
+  static constexpr int DY_SL = 25, X_SL = 20;                            // 16-byte slots per pixel (dy: 24 + 1 pad)
+  static constexpr int DY_PIXB = DY_SL * 16, X_PIXB = X_SL * 16;
+  static constexpr int DY_NS = TP * DY_SL, X_NS = TP * X_SL;
+  static constexpr int DY_NI = (DY_NS + 63) / 64, X_NI = (X_NS + 63) / 64;      // 38, 30
+  static constexpr int DY_BYTES = DY_NI * 1024, X_BYTES = X_NI * 1024;
+  static constexpr int LDS_BYTES = DY_BYTES + X_BYTES;
+  static constexpr int E = TM * TN;
+};
+
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad1t_kernel(Wgrad1wArgs a) {
+  using G = Wgrad1tGeom;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* dy_lds = smem;
+  unsigned char* x_lds = smem + G::DY_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int npairs = a.coTiles * a.ciTiles;
+  const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = bid % npairs, split = bid / npairs;
+  const int cot = pair % a.coTiles, cit = pair / a.coTiles;
+  const int t_begin = split * a.tilesPerSplit;
+  const int t_end = t_begin + a.tilesPerSplit < a.ntiles ? t_begin + a.tilesPerSplit : a.ntiles;
+  const bool want_bias = BIAS && cit == 0;
+  const int wo = wave & 1, wi = wave >> 1;
+
+  f32x4 acc[6][5];
+#pragma unroll
+  for (int ob = 0; ob < 6; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < 5; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;       // BIAS: thread tid < 192 sums out channel tid of the dy tiles
+
+  // transposing-read geometry: lane -> pixel 8 g + tq (+4 for the second half) of a 32-pixel k-step, channels 4 tp ..
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const unsigned char* abase = dy_lds + (8 * g + tq) * G::DY_PIXB + (wo * 96 + 4 * tp) * 2;
+  const unsigned char* bbase = x_lds + (8 * g + tq) * G::X_PIXB + (wi * 80 + 4 * tp) * 2;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int64_t p0 = (int64_t)t * G::TP;
+#pragma unroll
+    for (int j = 0; j < (G::DY_NI + 3) / 4; ++j) {
+      const int piece = wave + 4 * j;
+      if (piece < G::DY_NI) {
+        const int s = piece * 64 + lane;
+        const int px = s / G::DY_SL, c = s - px * G::DY_SL;
+        const bool ok = s < G::DY_NS && c < 24 && p0 + px < a.P;
+        const void* src = ok ? (const void*)(a.dy + (p0 + px) * a.lddy + cot * G::TM + c * 8) : (const void*)snws_zero_page;
+        glds16(src, dy_lds + piece * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < (G::X_NI + 3) / 4; ++j) {
+      const int piece = wave + 4 * j;
+      if (piece < G::X_NI) {
+        const int s = piece * 64 + lane;
+        const int px = s / G::X_SL, c = s - px * G::X_SL;
+        const bool ok = p0 + px < a.P && cit * G::TN + c * 8 < a.Cin;
+        const void* src = ok ? (const void*)(a.x + (p0 + px) * a.ldx + cit * G::TN + c * 8) : (const void*)snws_zero_page;
+        glds16(src, x_lds + piece * 1024);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (want_bias && tid < G::TM) {   // block-uniform branch; rare (the tap convolutions have no bias)
+      float s = 0.f;
+      for (int px = 0; px < G::TP; ++px)
+        s += (float)*reinterpret_cast<const bf16_t*>(dy_lds + px * G::DY_PIXB + tid * 2);
+      bsum += s;
+    }
+
+    // A fragments (dy, 6 per k-step) in two register sets, loaded a k-step ahead; B fragments (x) roll one ahead
+    bf16x8 af[2][6], bq[2];
+    auto load_a = [&](int s_) {
+#pragma unroll
+      for (int ob = 0; ob < 6; ++ob)
+        af[s_ & 1][ob] = tr_frag(abase + s_ * 32 * G::DY_PIXB + ob * 32, abase + s_ * 32 * G::DY_PIXB + ob * 32 + 4 * G::DY_PIXB);
+    };
+    auto load_b = [&](int f) {      // f = 5 * k-step + in block
+      const int s_ = f / 5, ib = f % 5;
+      bq[f & 1] = tr_frag(bbase + s_ * 32 * G::X_PIXB + ib * 32, bbase + s_ * 32 * G::X_PIXB + ib * 32 + 4 * G::X_PIXB);
+    };
+    load_a(0);
+    load_b(0);
+#pragma unroll
+    for (int f = 0; f < 15; ++f) {
+      const int s_ = f / 5, ib = f % 5;
+      if (f + 1 < 15) load_b(f + 1);
+      if (ib == 0 && s_ + 1 < 3) load_a(s_ + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ob = 0; ob < 6; ++ob)
+        acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s_ & 1][ob], bq[f & 1], acc[ob][ib], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- flush: D[out channel 16 ob + 4 (lane >> 4) + j][in channel 16 ib + (lane & 15)] of this wave's quadrant
+  if (a.part) {   // partial tile [ob][ib][j][wave][lane]
+    float* po = a.part + ((int64_t)split * npairs + pair) * G::E + tid;
+#pragma unroll
+    for (int ob = 0; ob < 6; ++ob)
+#pragma unroll
+      for (int ib = 0; ib < 5; ++ib)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) po[((ob * 5 + ib) * 4 + j) * 256] = acc[ob][ib][j];
+  } else {
+#pragma unroll
+    for (int ob = 0; ob < 6; ++ob)
+#pragma unroll
+      for (int ib = 0; ib < 5; ++ib)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = cot * G::TM + wo * 96 + ob * 16 + 4 * (lane >> 4) + j;
+          const int ci = cit * G::TN + wi * 80 + ib * 16 + (lane & 15);
+          if (ci < a.Cin && co < a.Cout) atomicAdd(a.dw + (int64_t)co * a.Cin + ci, acc[ob][ib][j]);
+        }
+  }
+  if (want_bias && tid < G::TM) {
+    if (a.part) a.pbias[((int64_t)split * a.coTiles + cot) * G::TM + tid] = bsum;
+    else if (cot * G::TM + tid < a.Cout) atomicAdd(a.dbias + cot * G::TM + tid, bsum);
+  }
+}
+
 // 3x3 wgrad over 64-wide in-channel tiles.  The generic kernel above reads one B fragment from LDS per MFMA, which
 // asks the LDS for its full 128 B/clk at the matrix pipe's peak rate.  Here a wave owns ALL 64 out channels (two A
 // fragments) x one 32-wide in-channel half x a group of 5 or 4 taps, so every B fragment feeds two MFMAs (7
@@ -1521,6 +1656,25 @@ bool wgrad9_m16() {
   return on;
 }
 
+template <bool BIAS>
+int launch_wgrad1t(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
+  using G = Wgrad1tGeom;
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1t_kernel<BIAS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    if (attr_set) attr_set->store(true, std::memory_order_release);
+  }
+  conv_wgrad1t_kernel<BIAS><<<grid, 256, G::LDS_BYTES, st>>>(a);
+  SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
+  return SNWS_OK;
+}
+
 template <bool BIAS, bool M16>
 int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<64, 9>;
@@ -1605,6 +1759,26 @@ WgradPlan wgrad_plan(const snws_conv_desc* d, bool det) {
     const int64_t padded = (int64_t)cdiv(d->C_in, 128) * 128 * cdiv(d->C_out, 128) * 128;
     p.wide = padded * 5 <= (int64_t)d->C_in * d->C_out * 6;
   }
+  static const bool no_t192 = getenv("SNWS_WGRAD1_T192") && atoi(getenv("SNWS_WGRAD1_T192")) == 0;   // A/B switch
+  static const bool force_t192 = getenv("SNWS_WGRAD1_T192") && atoi(getenv("SNWS_WGRAD1_T192")) == 2;    // tests: any size
+  if (c64 && taps == 1 && !generic && !narrow1 && !no_t192 && d->C_out % 192 == 0 && d->C_in >= 160 &&
+      (force_t192 || (int64_t)d->N * d->H * d->W >= 131072)) {
+    // the 192 x 160 tile: no padding for 576 outputs.  Measured on 320 -> 576, batch 16: 0.92 -> 0.49 ms at 256^2 (420 ->
+    // 794 TFLOP/s), 0.23 -> 0.16 ms at 128^2; below ~128 K pixels its 123 KB flush per workgroup outweighs the gain
+    // (0.054 -> 0.069 ms at 64^2) and the 64-wide kernel stays.
+    p.wide = true;
+    p.kind = 6; p.E = Wgrad1tGeom::E; p.TC = 192;
+    p.coTiles = d->C_out / 192; p.ciTiles = cdiv(d->C_in, 160);
+    p.npairs = p.coTiles * p.ciTiles;
+    const int64_t nt = ((int64_t)d->N * d->H * d->W + Wgrad1tGeom::TP - 1) / Wgrad1tGeom::TP;
+    p.ntiles = nt < (1ll << 31) ? (int)nt : -1;
+    int sp = (forced_blocks > 0 ? forced_blocks : 512) / p.npairs;   // one resident round of long workgroups
+    if (sp < 1) sp = 1;
+    if (sp > p.ntiles) sp = p.ntiles;
+    p.tilesPerSplit = cdiv(p.ntiles, sp);
+    p.splits = cdiv(p.ntiles, p.tilesPerSplit);
+    return p;
+  }
   if (p.wide) {
     p.kind = 3; p.E = 16384; p.TC = 128;
     p.coTiles = cdiv(d->C_out, 128); p.ciTiles = cdiv(d->C_in, 128);
@@ -1671,7 +1845,8 @@ int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void
     w.x = (const bf16_t*)x; w.dy = (const bf16_t*)dy; w.dw = dw_ohwi; w.dbias = dbias; w.part = part; w.pbias = pbias;
     w.P = (int64_t)d->N * d->H * d->W; w.Cin = d->C_in; w.Cout = d->C_out; w.ldx = d->ldx; w.lddy = d->ldy;
     w.coTiles = p.coTiles; w.ciTiles = p.ciTiles; w.ntiles = p.ntiles; w.tilesPerSplit = p.tilesPerSplit;
-    rc = dbias ? launch_wgrad1w<true>(w, grid, st) : launch_wgrad1w<false>(w, grid, st);
+    if (p.kind == 6) rc = dbias ? launch_wgrad1t<true>(w, grid, st) : launch_wgrad1t<false>(w, grid, st);
+    else rc = dbias ? launch_wgrad1w<true>(w, grid, st) : launch_wgrad1w<false>(w, grid, st);
   } else {
     WgradArgs a;
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw_ohwi; a.dbias = dbias; a.part = part; a.pbias = pbias;

@@ -10,7 +10,8 @@ namespace {
 // dw (O, taps, Cin); the bias partials are summed the same way and ADDED to dbias by one thread per channel (no
 // atomics: kernels on a stream run one after the other, so the result is bit-reproducible).
 // kind: 0 generic 64-wide, 1 generic C_in = 16 (its two pixel-row halves hold partial sums of the same outputs),
-//       2 wgrad1, 3 wgrad1w, 4 / 5 wgrad9 (32x32x16 / 16x16x32 form) - the register orders the kernels above store their tiles in.
+//       2 wgrad1, 3 wgrad1w, 4 / 5 wgrad9 (32x32x16 / 16x16x32 form), 6 wgrad1t - the register orders the kernels above store
+//       their tiles in.
 struct WgradReduceArgs {
   const float* part;
   const float* pbias;
@@ -22,6 +23,14 @@ struct WgradReduceArgs {
 };
 
 __device__ __forceinline__ bool wgrad_decode(int kind, int e, int cot, int cit, int& co, int& tap, int& ci) {
+  if (kind == 6) {          // wgrad1t (192 x 160 tile): [out block][in block][j][wave = (out half, in half)][lane]
+    const int lane = e & 63, wave = (e >> 6) & 3, q = e >> 8;
+    const int j = q & 3, blk = q >> 2, ob = blk / 5, ib = blk - ob * 5;
+    tap = 0;
+    co = cot * 192 + (wave & 1) * 96 + ob * 16 + 4 * (lane >> 4) + j;
+    ci = cit * 160 + (wave >> 1) * 80 + ib * 16 + (lane & 15);
+    return true;
+  }
   if (kind == 5) {          // wgrad9, 16x16x32 form: [tap][out block][in block][j][in-channel half][lane]
     const int lane = e & 63, cih = (e >> 6) & 1, q = e >> 7;
     const int j = q & 3, cbk = (q >> 2) & 1, ob = (q >> 3) & 3;

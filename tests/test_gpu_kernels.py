@@ -397,6 +397,10 @@ def test_conv2dws_mfma_matches_direct_kernels():
     (2, 64, 576, 16, 32, 1),     # 1x1, 64-wide kernel
     (2, 320, 16, 32, 32, 1),     # 1x1, the classification head's shape
     (2, 256, 128, 16, 16, 1),    # 1x1, 128-wide kernel
+    # 1x1 with a multiple of 192 outputs and >= 128 K pixels: the 192 x 160 tile of the tap convolutions
+    (1, 320, 576, 362, 363, 1),  # 6 pairs, a ragged last pixel tile
+    (1, 1024, 576, 362, 363, 1), # 7 in-channel tiles, the last one 64 wide
+    (1, 176, 192, 362, 363, 1),  # one out tile, an in-channel tail of 16
 ])
 def test_wgrad_deterministic_flush_matches_atomic_flush_and_repeats(case):
     """snws_conv_mfma_wgrad_det (partial tiles + fixed-order reduction) against snws_conv_mfma_wgrad (float atomics)
@@ -429,12 +433,17 @@ def test_wgrad_deterministic_flush_matches_atomic_flush_and_repeats(case):
         assert torch.equal(g, outs[0][0]) and torch.equal(b, outs[0][1])
     g, b = outs[0]
     assert relerr(g, g_at) < 1e-5 and relerr(b - 0.5, b_at) < 1e-5
-    # and against the definition, in float64 on the CPU
-    xr = x.float().cpu().double().permute(0, 3, 1, 2)
-    dyr = dy.float().cpu().double().permute(0, 3, 1, 2)
-    wr = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
-    torch.nn.functional.conv2d(xr, wr, None, 1, (k - 1) // 2).backward(dyr)
-    assert relerr(g.permute(0, 3, 1, 2), wr.grad) < 1e-5
+    # and against the definition, in float64 (on the CPU; the large 1x1 cases as one float64 product on the GPU)
+    if k == 1 and N * H * W > 100000:
+        want = torch.einsum("po,pi->oi", dy.double().reshape(-1, Cout), x.double().reshape(-1, Cin))
+        assert relerr(g.reshape(Cout, Cin), want) < 1e-5
+        assert relerr(b - 0.5, dy.double().reshape(-1, Cout).sum(0)) < 1e-5
+    else:
+        xr = x.float().cpu().double().permute(0, 3, 1, 2)
+        dyr = dy.float().cpu().double().permute(0, 3, 1, 2)
+        wr = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.conv2d(xr, wr, None, 1, (k - 1) // 2).backward(dyr)
+        assert relerr(g.permute(0, 3, 1, 2), wr.grad) < 1e-5
     with pytest.raises(ValueError, match="workspace"):
         L.call("snws_conv_mfma_wgrad_det", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), b.data_ptr(),
                ws.data_ptr(), nbytes - 16, None)
