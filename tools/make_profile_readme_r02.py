@@ -46,7 +46,7 @@ out = ["## Round 2", "",
        "per step, libsnws kernels %.1f %% of it (the rest: the loss's target handling, the synthetic batch and the optimizer-side "
        "torch element-wise kernels)." % (tot / 5e6, 100.0 * ours / tot),
        "* `r02_bench_gpus1.json` - the JSON line of the default `python bench.py` run: **%.1f images/s**, %.2f ms/step on this "
-       "box (boxes of the pool differ by about 2 %%; ten-step runs of the same tree gave 290.7 - 292.9); `roofline.frac` %.3f "
+       "box (boxes of the pool differ by about 2 %%: same-box A/B runs are what the per-change numbers in DESIGN.md come from); `roofline.frac` %.3f "
        "(HIP events: %.1f us per launch of the dominant kernel; the rocprofv3 run above averages %.1f us over the same %d launches "
        "-> %.0f TFLOP/s = %.3f of 2500); `stream_ceiling` = the copy rate measured in the same run (%.2f TB/s)."
        % (b["value"], b["ms_per_step"], rf["frac"], rf["avg_launch_ms"] * 1e3, avg, calls, rf["flops_per_launch"] / avg / 1e6,
