@@ -1180,10 +1180,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1t_kernel(Wgrad1wArgs a) {
 // of k-step s+1 are read while the MFMAs of step s run (two register sets).
 // M16: v_mfma_f32_16x16x32_bf16 (k-step = one 32-pixel tile row, 4 x 2 output blocks of 16 x 16 per tap) instead of
 // 32x32x16: the same fragment reads and matrix cycles per pixel, but the chip holds a higher clock under this shape.
-template <bool FIVE, bool BIAS, bool M16>
+// QW (with M16): a wave owns all 64 out channels x one 16-wide in-channel QUARTER x all nine taps.  The B fragment of
+// (halo row rho, kw) then serves the three taps (kh, kw) at the k-steps rho - kh, so a tile needs 30 B fragments
+// instead of 72 (62 fragment reads per 288 matrix instructions instead of 100), and the four waves carry equal work.
+// The walk is over halo rows: A fragments of the three live k-steps sit in a rolling three-slot set, the next halo
+// row's B fragments and the next k-step's A fragments are read while the current row multiplies.
+template <bool FIVE, bool BIAS, bool M16, bool QW = false>
 __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* smem, int bid) {
+  static_assert(!QW || (M16 && FIVE), "the quarter-wave form exists for the 16x16x32 shape only");
   using G = WgGeom<64, 9>;
-  constexpr int NT = FIVE ? 5 : 4, T0 = FIVE ? 0 : 5;
+  constexpr int NT = QW ? 9 : FIVE ? 5 : 4, T0 = (QW || FIVE) ? 0 : 5;
   unsigned char* dy_lds = smem;
   unsigned char* x_lds = smem + G::DY_BYTES;
 
@@ -1198,15 +1204,16 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   const int ci_half = wave & 1;
   const bool want_bias = BIAS && cit == 0;
 
+  constexpr int NCB = QW ? 1 : 2;   // 16-wide in-channel blocks per wave
   f32x16 acc[M16 ? 1 : NT][M16 ? 1 : 2];
-  f32x4 acc16[M16 ? NT : 1][M16 ? 4 : 1][M16 ? 2 : 1];    // [tap][out block of 16][in block of 16]
+  f32x4 acc16[M16 ? NT : 1][M16 ? 4 : 1][M16 ? NCB : 1];    // [tap][out block of 16][in block of 16]
   if constexpr (M16) {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-        for (int cbk = 0; cbk < 2; ++cbk) acc16[i][ob][cbk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cbk = 0; cbk < NCB; ++cbk) acc16[i][ob][cbk] = f32x4{0.f, 0.f, 0.f, 0.f};
   } else {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -1233,12 +1240,14 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   }
   // x halo: pixel q = (row + kh)*34 + col + kw; swizzle bit (q >> 1) & 1 = (((cb0 + kw) >> 1) + row + kh) & 1, so an
   // odd tile row flips chunk bit 2 (byte-offset bit 6) relative to an even one
-  const unsigned char* bbase[NT][2];
+  // (QW: one base per kw and halo-row parity, the halo row enters as an immediate)
+  constexpr int NBB = QW ? 3 : NT;
+  const unsigned char* bbase[NBB][2];
   {
-    const int bch = ci_half * 32 + rb + 4 * gp;
+    const int bch = QW ? wave * 16 + 4 * gp : ci_half * 32 + rb + 4 * gp;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int kh = (T0 + i) / 3, kw = (T0 + i) % 3;
+    for (int i = 0; i < NBB; ++i) {
+      const int kh = QW ? 0 : (T0 + i) / 3, kw = QW ? i : (T0 + i) % 3;
       const int sw = ((((cb0 + kw) >> 1) + kh) & 1) << 2;
       const int off = (kh * G::HWd + cb0 + kw) * 128 + (((bch >> 3) ^ sw) * 16) + (bch & 7) * 2;
       bbase[i][0] = x_lds + off;
@@ -1343,7 +1352,50 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
       }
     }
 
-    if constexpr (M16) {
+    if constexpr (QW) {
+      bf16x8 af[3][4], bq[2][3];
+      auto load_a1 = [&](int ks, int ob) {
+        const int a_imm = ks * 32 * 128 + (ob & 1) * 32;
+        af[ks % 3][ob] = tr_frag(abase[ob >> 1] + a_imm, abase[ob >> 1] + a_imm + 512);
+      };
+      auto load_b1 = [&](int rho, int kw) {
+        const int b_imm = rho * G::HWd * 128;
+        bq[rho & 1][kw] = tr_frag(bbase[kw][rho & 1] + b_imm, bbase[kw][rho & 1] + b_imm + 512);
+      };
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) load_a1(0, ob);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) load_b1(0, kw);
+#pragma unroll
+      for (int rho = 0; rho < 10; ++rho) {
+        // groups of this halo row in the order kh = 2, 1, 0 (the oldest k-step first: its A slot is refilled next)
+        const int nkh2 = (rho >= 2 && rho - 2 < 8) ? 3 : 0;
+        const int ngroups = ((rho >= 2 && rho - 2 < 8) ? 3 : 0) + ((rho >= 1 && rho - 1 < 8) ? 3 : 0) + (rho < 8 ? 3 : 0);
+        const bool want_a = rho + 1 < 8, want_b = rho + 1 < 10;
+        const int a_per = (4 + (ngroups - nkh2) - 1) / (ngroups - nkh2 > 0 ? ngroups - nkh2 : 1);
+        int gi = 0, a_next = 0;
+#pragma unroll
+        for (int kh = 2; kh >= 0; --kh) {
+          const int ks = rho - kh;
+          if (ks < 0 || ks >= 8) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            if (want_b && gi < 3) load_b1(rho + 1, gi);
+            if (want_a && gi >= nkh2) {
+#pragma unroll
+              for (int u = 0; u < a_per; ++u)
+                if (a_next < 4) { load_a1(rho + 1, a_next); ++a_next; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+              acc16[kh * 3 + kw][ob][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks % 3][ob], bq[rho & 1][kw], acc16[kh * 3 + kw][ob][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ++gi;
+          }
+        }
+      }
+    } else if constexpr (M16) {
       // k-step = tile row (32 pixels).  Per (k-step, tap, in block) pair one B fragment feeds the four out blocks;
       // the B fragment of pair f+2 and the A fragments of the next k-step are read while the MFMAs of pair f run.
       // (in block 1 sits 32 bytes behind block 0: the chunk swizzle only touches chunk bit 2)
@@ -1407,27 +1459,29 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
   if constexpr (M16) {
     // D[out channel 16 ob + 4 (lane >> 4) + j][in channel 32 half + 16 cbk + (lane & 15)]
+    // (QW: the wave's in-channel quarter is block (wave & 1) of half (wave >> 1) - the same partial-tile layout)
+    const int fl_half = QW ? wave >> 1 : ci_half, fl_cb0 = QW ? wave & 1 : 0;
     if (a.part) {   // partial tile [tap][ob][cbk][j][in-channel half][lane]
-      float* o = a.part + ((int64_t)split * npairs + pair) * 36864 + ci_half * 64 + lane;
+      float* o = a.part + ((int64_t)split * npairs + pair) * 36864 + fl_half * 64 + lane;
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-          for (int cbk = 0; cbk < 2; ++cbk)
+          for (int cbk = 0; cbk < NCB; ++cbk)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[((((T0 + i) * 4 + ob) * 2 + cbk) * 4 + j) * 128] = acc16[i][ob][cbk][j];
+            for (int j = 0; j < 4; ++j) o[((((T0 + i) * 4 + ob) * 2 + cbk + fl_cb0) * 4 + j) * 128] = acc16[i][ob][cbk][j];
     } else {
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-          for (int cbk = 0; cbk < 2; ++cbk)
+          for (int cbk = 0; cbk < NCB; ++cbk)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int co = cot * 64 + ob * 16 + 4 * (lane >> 4) + j;
-              const int ci16 = cit * 64 + ci_half * 32 + cbk * 16 + (lane & 15);
+              const int ci16 = cit * 64 + fl_half * 32 + (cbk + fl_cb0) * 16 + (lane & 15);
               if (ci16 < a.Cin && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + (T0 + i)) * a.Cin + ci16, acc16[i][ob][cbk][j]);
             }
     }
@@ -1471,6 +1525,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(WgradArgs a) {
   const int tg = __builtin_amdgcn_readfirstlane(((wave >> 1) ^ (bid >> 5)) & 1);
   if (tg == 0) wgrad9_body<true, BIAS, M16>(a, smem, bid);
   else wgrad9_body<false, BIAS, M16>(a, smem, bid);
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad9q_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  wgrad9_body<true, BIAS, true, true>(a, smem, (int)xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // ------------------------------------------------------------------------------------------------- host
@@ -1675,6 +1735,32 @@ int launch_wgrad1t(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
   return SNWS_OK;
 }
 
+// SNWS_WGRAD9_QW = 0 selects the (in-channel half x tap group) wave split of the 16x16x32 3x3 wgrad kernel instead of
+// the (in-channel quarter x all taps) one (A/B measurements)
+bool wgrad9_qw() {
+  static const bool on = !(getenv("SNWS_WGRAD9_QW") && atoi(getenv("SNWS_WGRAD9_QW")) == 0);
+  return on;
+}
+
+template <bool BIAS>
+int launch_wgrad9q(const WgradArgs& a, unsigned grid, hipStream_t st) {
+  using G = WgGeom<64, 9>;
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9q_kernel<BIAS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    if (attr_set) attr_set->store(true, std::memory_order_release);
+  }
+  conv_wgrad9q_kernel<BIAS><<<grid, 256, G::LDS_BYTES, st>>>(a);
+  SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
+  return SNWS_OK;
+}
+
 template <bool BIAS, bool M16>
 int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<64, 9>;
@@ -1854,7 +1940,8 @@ int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void
     a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
     a.coTiles = p.coTiles; a.ciTiles = p.ciTiles; a.tilesPerSplit = p.tilesPerSplit;
     if (p.kind == 4 || p.kind == 5) {
-      if (p.kind == 5) rc = dbias ? launch_wgrad9<true, true>(a, grid, st) : launch_wgrad9<false, true>(a, grid, st);
+      if (p.kind == 5 && wgrad9_qw()) rc = dbias ? launch_wgrad9q<true>(a, grid, st) : launch_wgrad9q<false>(a, grid, st);
+      else if (p.kind == 5) rc = dbias ? launch_wgrad9<true, true>(a, grid, st) : launch_wgrad9<false, true>(a, grid, st);
       else rc = dbias ? launch_wgrad9<true, false>(a, grid, st) : launch_wgrad9<false, false>(a, grid, st);
     }
     else if (p.kind == 2) rc = dbias ? launch_wgrad1<true>(a, grid, st) : launch_wgrad1<false>(a, grid, st);
