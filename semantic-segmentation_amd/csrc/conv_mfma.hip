@@ -44,6 +44,25 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+#ifdef SNWS_TIMING
+// Diagnostics build (-DSNWS_TIMING): shader-clock cycles the forward kernel's workgroups spend waiting for staged data,
+// in the matrix phase and in the epilogue, summed over workgroups (wave 0 only); snws_dbg_read copies and clears them.
+__device__ unsigned long long snws_dbg[8];
+#define SNWS_T(var) const long long var = clock64()
+#else
+#define SNWS_T(var)
+#endif
+
+// Progressive wave priority.  Two workgroups share a CU so that one stages while the other multiplies; with equal
+// priorities two waves that multiply at the same time share the matrix pipe evenly, finish together and then stage
+// together - the pipe idles for a whole staging latency.  A wave that is further into its matrix phase outranks one
+// that has just begun, so the leader finishes at full speed (first come, first served) and the pair falls into
+// alternation.  level: 0 outside the matrix phase, 1..3 by progress.
+template <int LEVEL>
+__device__ __forceinline__ void prio_step(int on) {
+  if (on) __builtin_amdgcn_s_setprio(LEVEL);
+}
+
 // XCD-aware block id: blocks that are dealt to the same XCD (bid % 8) get consecutive logical ids, so tiles that
 // share an input patch or a filter slab also share an L2.  Bijective for any grid size.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
@@ -74,6 +93,7 @@ struct FwdArgs {
   int64_t ldx, ldy;
   int tilesX, tilesY, coTiles, nchunks;
   int accumulate;     // != 0: y += result (a gradient with several contributors: a later contributor adds in place)
+  int prio;           // != 0: the wave priority rises as a chunk's matrix work progresses (see prio_step)
 };
 // arguments of the dgrad variant whose epilogue also reduces for the SwitchNorm layers behind its output
 struct FwdArgsBwr : FwdArgs {
@@ -267,6 +287,9 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
       const int kw = st / NR, rho = st % NR;
+      if (st == 0) prio_step<1>(a.prio);
+      if (st == NSTEP / 3) prio_step<2>(a.prio);
+      if (st == 2 * NSTEP / 3) prio_step<3>(a.prio);
       if (st + 1 < NSTEP) load_b(st + 1);
       if (rho + 1 < KHN) load_a(kw, rho + 1);                 // first used by the next row
       if (rho == NR - 1 && kw + 1 < KWN) load_a(kw + 1, 0);   // kh = 0 of this kw was last used at row 3
@@ -283,18 +306,30 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    prio_step<0>(a.prio);
   };
   auto compute = [&](int so) {
     if constexpr (M16) compute16(so); else compute32(so);
   };
 
+#ifdef SNWS_TIMING
+  long long dbg_wait = 0, dbg_comp = 0;
+  const long long dbg_t0 = clock64();
+#endif
   if (!DB) {
     for (int ch = 0; ch < a.nchunks; ++ch) {
+      SNWS_T(ta);
       stage(ch, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      SNWS_T(tb);
       compute(0);
       __syncthreads();
+#ifdef SNWS_TIMING
+      const long long tc = clock64();
+      dbg_wait += tb - ta;
+      dbg_comp += tc - tb;
+#endif
     }
   } else {
     stage(0, 0);
@@ -521,6 +556,15 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
       o[1] = q;
     }
   }
+#ifdef SNWS_TIMING
+  if (tid == 0) {
+    const long long te = clock64();
+    atomicAdd(&snws_dbg[0], (unsigned long long)dbg_wait);
+    atomicAdd(&snws_dbg[1], (unsigned long long)dbg_comp);
+    atomicAdd(&snws_dbg[2], (unsigned long long)(te - dbg_t0 - dbg_wait - dbg_comp));
+    atomicAdd(&snws_dbg[3], 1ull);
+  }
+#endif
   // ---- the output tile, last: nothing in this workgroup waits for these stores
   if (lane_ok) {
     if (a.accumulate) {     // kernel-uniform: add to what the destination holds (f32 sum of the two bf16 values, rounded once)
@@ -565,6 +609,7 @@ struct WgradArgs {
   int N, H, W, Cin, Cout;   // Cin: channels of x that take part (multiple of 16); dw rows have Cin entries
   int64_t ldx, lddy;
   int tilesX, tilesY, coTiles, ciTiles, tilesPerSplit;
+  int prio;                 // != 0: the wave priority rises as a tile's matrix work progresses (see prio_step)
 };
 
 constexpr int WG_TH = 8, WG_TW = 32;
@@ -1185,7 +1230,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1t_kernel(Wgrad1wArgs a) {
 // instead of 72 (62 fragment reads per 288 matrix instructions instead of 100), and the four waves carry equal work.
 // The walk is over halo rows: A fragments of the three live k-steps sit in a rolling three-slot set, the next halo
 // row's B fragments and the next k-step's A fragments are read while the current row multiplies.
-template <bool FIVE, bool BIAS, bool M16, bool QW = false>
+template <bool FIVE, bool BIAS, bool M16, bool QW = false, bool PRIO = false>
 __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* smem, int bid) {
   static_assert(!QW || (M16 && FIVE), "the quarter-wave form exists for the 16x16x32 shape only");
   using G = WgGeom<64, 9>;
@@ -1372,6 +1417,11 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
         const int nkh2 = (rho >= 2 && rho - 2 < 8) ? 3 : 0;
         const int ngroups = ((rho >= 2 && rho - 2 < 8) ? 3 : 0) + ((rho >= 1 && rho - 1 < 8) ? 3 : 0) + (rho < 8 ? 3 : 0);
         const bool want_a = rho + 1 < 8, want_b = rho + 1 < 10;
+        if constexpr (PRIO) {     // (compile-time: a branch here would cut the unrolled walk into blocks and spill)
+          if (rho == 0) __builtin_amdgcn_s_setprio(1);
+          if (rho == 4) __builtin_amdgcn_s_setprio(2);
+          if (rho == 7) __builtin_amdgcn_s_setprio(3);
+        }
         const int a_per = (4 + (ngroups - nkh2) - 1) / (ngroups - nkh2 > 0 ? ngroups - nkh2 : 1);
         int gi = 0, a_next = 0;
 #pragma unroll
@@ -1395,6 +1445,7 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
           }
         }
       }
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     } else if constexpr (M16) {
       // k-step = tile row (32 pixels).  Per (k-step, tap, in block) pair one B fragment feeds the four out blocks;
       // the B fragment of pair f+2 and the A fragments of the next k-step are read while the MFMAs of pair f run.
@@ -1527,10 +1578,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(WgradArgs a) {
   else wgrad9_body<false, BIAS, M16>(a, smem, bid);
 }
 
-template <bool BIAS>
+template <bool BIAS, bool PRIO>
 __global__ __launch_bounds__(256, 2) void conv_wgrad9q_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  wgrad9_body<true, BIAS, true, true>(a, smem, (int)xcd_remap(blockIdx.x, gridDim.x));
+  wgrad9_body<true, BIAS, true, true, PRIO>(a, smem, (int)xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // ------------------------------------------------------------------------------------------------- host
@@ -1549,6 +1600,12 @@ int check_mfma_desc(const snws_conv_desc* d, const char* fn) {
   if ((int64_t)d->H * d->W * d->ldx * 2 >= 0xFFFFFFFFll || (int64_t)d->H * d->W * d->ldy * 2 >= 0xFFFFFFFFll)
     SNWS_UNSUPPORTED("%s: one image exceeds 4 GiB", fn);
   return SNWS_OK;
+}
+
+// SNWS_PRIO = 0 switches the progressive wave priority of the matrix phases off (A/B measurements)
+int conv_prio() {
+  static const int on = getenv("SNWS_PRIO") ? atoi(getenv("SNWS_PRIO")) != 0 : 1;
+  return on;
 }
 
 // SNWS_CONV_DB=0/1 overrides the default choice between the single- and double-buffered forward kernels
@@ -1616,6 +1673,7 @@ int run_fwd_like(const char* fn, int N, int H, int W, int c_in_run, int c_out_ru
   a.N = N; a.H = H; a.W = W; a.Cout = c_out_run; a.ldx = ldx; a.ldy = ldy;
   a.tilesX = cdiv(W, FWD_TW); a.tilesY = cdiv(H, FWD_TH); a.coTiles = g.c_out_p / 64; a.nchunks = g.nchunks;
   a.accumulate = accumulate;
+  a.prio = conv_prio();
   bool bwr = false;
   if (n_segs > 0) {
     if (a.coTiles > MAX_BWR_TILES) SNWS_UNSUPPORTED("%s: more than %d output-channel tiles", fn, MAX_BWR_TILES * 64);
@@ -1742,13 +1800,13 @@ bool wgrad9_qw() {
   return on;
 }
 
-template <bool BIAS>
+template <bool BIAS, bool PRIO>
 int launch_wgrad9q(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<64, 9>;
   static PerDeviceOnce once;
   std::atomic<bool>* const attr_set = once.flag();
   if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9q_kernel<BIAS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9q_kernel<BIAS, PRIO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1756,7 +1814,7 @@ int launch_wgrad9q(const WgradArgs& a, unsigned grid, hipStream_t st) {
     }
     if (attr_set) attr_set->store(true, std::memory_order_release);
   }
-  conv_wgrad9q_kernel<BIAS><<<grid, 256, G::LDS_BYTES, st>>>(a);
+  conv_wgrad9q_kernel<BIAS, PRIO><<<grid, 256, G::LDS_BYTES, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
   return SNWS_OK;
 }
@@ -1781,6 +1839,15 @@ int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef SNWS_TIMING
+extern "C" int snws_dbg_read(unsigned long long* out8) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(snws_dbg), sizeof(snws_dbg)) != hipSuccess) return -1;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(snws_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int snws_conv_mfma_tiles(int H, int W) { return cdiv(H, FWD_TH) * cdiv(W, FWD_TW); }
 
@@ -1939,8 +2006,12 @@ int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->C_in; a.Cout = d->C_out; a.ldx = d->ldx; a.lddy = d->ldy;
     a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
     a.coTiles = p.coTiles; a.ciTiles = p.ciTiles; a.tilesPerSplit = p.tilesPerSplit;
+    a.prio = conv_prio();
     if (p.kind == 4 || p.kind == 5) {
-      if (p.kind == 5 && wgrad9_qw()) rc = dbias ? launch_wgrad9q<true>(a, grid, st) : launch_wgrad9q<false>(a, grid, st);
+      if (p.kind == 5 && wgrad9_qw()) {
+        if (a.prio) rc = dbias ? launch_wgrad9q<true, true>(a, grid, st) : launch_wgrad9q<false, true>(a, grid, st);
+        else rc = dbias ? launch_wgrad9q<true, false>(a, grid, st) : launch_wgrad9q<false, false>(a, grid, st);
+      }
       else if (p.kind == 5) rc = dbias ? launch_wgrad9<true, true>(a, grid, st) : launch_wgrad9<false, true>(a, grid, st);
       else rc = dbias ? launch_wgrad9<true, false>(a, grid, st) : launch_wgrad9<false, false>(a, grid, st);
     }
