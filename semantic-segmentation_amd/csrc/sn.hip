@@ -8,11 +8,15 @@
 // Moments are accumulated as sums of (x - shift) and (x - shift)^2 per tile in f32 and combined across tiles in
 // f64, in a fixed order, so results are bit-reproducible run to run.
 #include "common.h"
+#include <stdlib.h>
 #include "sn_ctx.h"
 
 namespace {
 
 constexpr int SN_THREADS = 256;
+// pixel rows a thread of the backward apply pass keeps in flight (three tensors per row with a stored-output mask)
+template <bool YMASK>
+constexpr int SN_BWD_ROWS = YMASK ? 2 : 4;
 
 struct SnMap {  // how 256 threads cover (pixel rows) x (channel groups)
   int CG, cgb, PR, active;
@@ -242,6 +246,24 @@ __global__ __launch_bounds__(256) void sn_mix_b_kernel(float* __restrict__ ctx, 
   ctx[o.scale + i] = gamma[c] * rstd;
 }
 
+// V consecutive per-channel coefficients: 16-byte loads when the address allows (a workgroup's first data loads wait
+// behind these, so their count is the start-up latency of every workgroup of the streaming passes)
+template <int V>
+__device__ __forceinline__ void load_coef(const float* __restrict__ p, float (&out)[V]) {
+  if constexpr (V % 4 == 0) {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < V / 4; ++k) {
+        const float4 q = reinterpret_cast<const float4*>(p)[k];
+        out[4 * k] = q.x; out[4 * k + 1] = q.y; out[4 * k + 2] = q.z; out[4 * k + 3] = q.w;
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) out[v] = p[v];
+}
+
 // ------------------------------------------------------------------------------------------- pass 2: normalise
 template <typename T, int V, bool RELU, bool RES>
 __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
@@ -251,9 +273,14 @@ __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restric
                                                               int PT, SnMap m, const float* __restrict__ post = nullptr) {
   // post: optional non-negative multiplier per (image, channel) on the OUTPUT (a feature-dropout mask after the
   // activation): act(z) * s = act(z * s) for s >= 0, so it is folded into the coefficients (no residual then)
+  // PT > 0: the workgroup streams the contiguous pixel range [t PT, (t+1) PT).  PT == 0: the workgroups of an image
+  // interleave pieces of 4 PR pixels (piece t, t + T, ...), so the resident workgroups sweep one compact window of
+  // each tensor instead of thousands of far-apart streams (DRAM page locality).
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const int64_t p0 = (int64_t)t * PT;
-  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  const int64_t PS = 4 * (int64_t)m.PR;
+  const int64_t p0 = PT > 0 ? (int64_t)t * PT : (int64_t)t * PS;
+  const int64_t p1 = PT > 0 ? (p0 + PT < HW ? p0 + PT : HW) : HW;
+  const int64_t pstep = PT > 0 ? PS : (int64_t)gridDim.x * PS;
   const CtxOff o = ctx_off(N, C);
   const T* xn = x + (int64_t)n * HW * ldx;
   T* yn = y + (int64_t)n * HW * ldy;
@@ -264,21 +291,24 @@ __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restric
     const int cg = cg0 + cgl;
     if (cg >= m.CG) continue;
     float mu[V], sc[V], be[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const int64_t i = (int64_t)n * C + cg * V + v;
-      mu[v] = ctx[o.mean + i];
-      sc[v] = ctx[o.scale + i];
-      be[v] = beta[cg * V + v];
+    {
+      const int64_t i0 = (int64_t)n * C + cg * V;
+      load_coef<V>(ctx + o.mean + i0, mu);
+      load_coef<V>(ctx + o.scale + i0, sc);
+      load_coef<V>(beta + cg * V, be);
       if (post) {
-        const float pm = post[i];
-        sc[v] *= pm;
-        be[v] *= pm;
+        float pm[V];
+        load_coef<V>(post + i0, pm);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          sc[v] *= pm[v];
+          be[v] *= pm[v];
+        }
       }
     }
     const int64_t co = (int64_t)cg * V;
     int64_t p = p0 + prow;
-    for (; p + 3 * m.PR < p1; p += 4 * m.PR) {
+    for (; p + 3 * m.PR < p1; p += pstep) {
       float a[4][V];
 #pragma unroll
       for (int u = 0; u < 4; ++u) VecNT<T, V>::load(xn + (p + u * m.PR) * ldx + co, a[u]);
@@ -298,6 +328,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restric
         VecNT<T, V>::store(yn + (p + u * m.PR) * ldy + co, a[u]);
       }
     }
+    // (the ragged end: at most one piece, and only in the workgroup whose walk reaches it)
     for (; p < p1; p += m.PR) {
       float a[V], r[V];
       VecNT<T, V>::load(xn + p * ldx + co, a);
@@ -623,9 +654,13 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
                                                                   T* __restrict__ dres = nullptr, int64_t lddr = 0,
                                                                   const float* __restrict__ post = nullptr) {
   // post: the forward's per-(image, channel) output multiplier; the incoming gradient is scaled by it after the mask
+  // PT == 0: interleaved pieces of U PR pixels (see sn_apply_kernel)
+  constexpr int U = SN_BWD_ROWS<YMASK>;
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const int64_t p0 = (int64_t)t * PT;
-  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  const int64_t PS = U * (int64_t)m.PR;
+  const int64_t p0 = PT > 0 ? (int64_t)t * PT : (int64_t)t * PS;
+  const int64_t p1 = PT > 0 ? (p0 + PT < HW ? p0 + PT : HW) : HW;
+  const int64_t pstep = PT > 0 ? PS : (int64_t)gridDim.x * PS;
   const CtxOff o = ctx_off(N, C);
   const CtxbOff ob = ctxb_off(N, C);
   const T* xn = x + (int64_t)n * HW * ldx;
@@ -639,48 +674,48 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
     const int cg = cg0 + cgl;
     if (cg >= m.CG) continue;
     float mu[V], sc[V], be[V], Bc[V], Kc[V], sg[V];
+    {
+      const int64_t i0 = (int64_t)n * C + cg * V;
+      load_coef<V>(ctx + o.mean + i0, mu);
+      load_coef<V>(ctx + o.scale + i0, sc);
+      load_coef<V>(beta + cg * V, be);
+      load_coef<V>(ctxb + ob.B + i0, Bc);
+      load_coef<V>(ctxb + ob.K + i0, Kc);
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const int64_t i = (int64_t)n * C + cg * V + v;
-      mu[v] = ctx[o.mean + i];
-      sc[v] = ctx[o.scale + i];
-      be[v] = beta[cg * V + v];
-      Bc[v] = ctxb[ob.B + i];
-      Kc[v] = ctxb[ob.K + i];
-      sg[v] = post ? sc[v] * post[i] : sc[v];
+      for (int v = 0; v < V; ++v) sg[v] = sc[v];
+      if (post) {
+        float pm[V];
+        load_coef<V>(post + i0, pm);
+#pragma unroll
+        for (int v = 0; v < V; ++v) sg[v] = sc[v] * pm[v];
+      }
     }
     const int64_t co = (int64_t)cg * V;
     int64_t p = p0 + prow;
-    for (; p + m.PR < p1; p += 2 * m.PR) {
-      float a0[V], a1[V], g0[V], g1[V], y0[V], y1[V];
-      VecNT<T, V>::load(xn + p * ldx + co, a0);
-      VecNT<T, V>::load(xn + (p + m.PR) * ldx + co, a1);
-      VecNT<T, V>::load(dn + p * lddy + co, g0);
-      VecNT<T, V>::load(dn + (p + m.PR) * lddy + co, g1);
+    for (; p + (U - 1) * m.PR < p1; p += pstep) {
+      float a[U][V], g[U][V], yv[YMASK ? U : 1][V];
+#pragma unroll
+      for (int u = 0; u < U; ++u) VecNT<T, V>::load(xn + (p + u * m.PR) * ldx + co, a[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) VecNT<T, V>::load(dn + (p + u * m.PR) * lddy + co, g[u]);
       if (YMASK) {
-        VecNT<T, V>::load(yn + p * ldy + co, y0);
-        VecNT<T, V>::load(yn + (p + m.PR) * ldy + co, y1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) VecNT<T, V>::load(yn + (p + u * m.PR) * ldy + co, yv[YMASK ? u : 0]);
       }
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
+      for (int u = 0; u < U; ++u) {
         if (RELU) {
-          bool k0 = YMASK ? (y0[v] > 0.f) : (fmaf(a0[v] - mu[v], sc[v], be[v]) > 0.f);
-          bool k1 = YMASK ? (y1[v] > 0.f) : (fmaf(a1[v] - mu[v], sc[v], be[v]) > 0.f);
-          g0[v] = k0 ? g0[v] : 0.f;
-          g1[v] = k1 ? g1[v] : 0.f;
-        }
-      }
-      if (DRES) {
-        VecNT<T, V>::store(rn + p * lddr + co, g0);
-        VecNT<T, V>::store(rn + (p + m.PR) * lddr + co, g1);
-      }
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        g0[v] = fmaf(sg[v], g0[v], fmaf(Bc[v], a0[v], Kc[v]));
-        g1[v] = fmaf(sg[v], g1[v], fmaf(Bc[v], a1[v], Kc[v]));
+          for (int v = 0; v < V; ++v) {
+            const bool k = YMASK ? (yv[YMASK ? u : 0][v] > 0.f) : (fmaf(a[u][v] - mu[v], sc[v], be[v]) > 0.f);
+            g[u][v] = k ? g[u][v] : 0.f;
+          }
+        }
+        if (DRES) VecNT<T, V>::store(rn + (p + u * m.PR) * lddr + co, g[u]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) g[u][v] = fmaf(sg[v], g[u][v], fmaf(Bc[v], a[u][v], Kc[v]));
+        VecNT<T, V>::store(on + (p + u * m.PR) * lddx + co, g[u]);
       }
-      VecNT<T, V>::store(on + p * lddx + co, g0);
-      VecNT<T, V>::store(on + (p + m.PR) * lddx + co, g1);
     }
     for (; p < p1; p += m.PR) {
       float a0[V], g0[V], y0[V];
@@ -736,12 +771,27 @@ int run_stats(const void* x, int N, int64_t HW, int C, int64_t ldx, float* part,
   return SNWS_OK;
 }
 
+// SNWS_SN_INTERLEAVE = 0 gives every workgroup of the apply passes one contiguous pixel range instead of interleaved
+// pieces (A/B measurements)
+inline bool sn_interleave() {
+  static const bool on = !(getenv("SNWS_SN_INTERLEAVE") && atoi(getenv("SNWS_SN_INTERLEAVE")) == 0);
+  return on;
+}
+// grid of an apply pass whose workgroups interleave pieces of `piece` pixels: the workgroup count of the contiguous
+// walk (64 KB of a tensor per workgroup, at most 4096 workgroups: shorter workgroups spend their time loading
+// coefficients), never more than there are pieces
+inline int sn_apply_tiles(int N, int64_t HW, int C, int64_t piece) {
+  const int64_t t = sn_tiles(N, HW, C), np = cdiv64(HW, piece);
+  return (int)(np < t ? np : t);
+}
+
 template <typename T, int V>
 int run_apply(const void* x, int64_t ldx, void* y, int64_t ldy, const void* res, int64_t ldr, const float* ctx,
               const float* beta, int N, int64_t HW, int C, int relu, hipStream_t st, const float* post = nullptr) {
   const SnMap m = sn_map(C, V);
-  const int T_ = sn_tiles(N, HW, C);
-  const int PT = (int)cdiv64(HW, T_);
+  const bool il = sn_interleave();
+  const int T_ = il ? sn_apply_tiles(N, HW, C, 4 * m.PR) : sn_tiles(N, HW, C);
+  const int PT = il ? 0 : (int)cdiv64(HW, T_);
   dim3 grid(T_, N);
 #define AP(R, S) sn_apply_kernel<T, V, R, S><<<grid, SN_THREADS, 0, st>>>((const T*)x, ldx, (T*)y, ldy, (const T*)res, ldr, ctx, beta, N, HW, C, PT, m, post)
   if (relu) { if (res) AP(true, true); else AP(true, false); }
@@ -773,8 +823,9 @@ int run_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, cons
                   int64_t lddx, const float* ctx, const float* ctxb, const float* beta, int N, int64_t HW, int C,
                   int relu, hipStream_t st, void* dres = nullptr, int64_t lddr = 0, const float* post = nullptr) {
   const SnMap m = sn_map(C, V);
-  const int T_ = sn_tiles(N, HW, C);
-  const int PT = (int)cdiv64(HW, T_);
+  const bool il = sn_interleave();
+  const int T_ = il ? sn_apply_tiles(N, HW, C, (ym ? SN_BWD_ROWS<true> : SN_BWD_ROWS<false>) * m.PR) : sn_tiles(N, HW, C);
+  const int PT = il ? 0 : (int)cdiv64(HW, T_);
   dim3 grid(T_, N);
 #define BA(R, Y) sn_bwd_apply_kernel<T, V, R, Y><<<grid, SN_THREADS, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, (T*)dx, lddx, ctx, ctxb, beta, N, HW, C, PT, m, nullptr, 0, post)
   if (dres)    // the caller checked relu && ym
