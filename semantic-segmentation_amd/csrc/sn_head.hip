@@ -14,6 +14,7 @@
 // 15, channel octet h = lane >> 4) holds channels 8h .. 8h+7 of the 32 - one 16-byte load, and exactly the operand /
 // result layout of two 16x16x16 MFMAs whose contraction (forward) or output rows (backward) are permuted accordingly.
 #include "common.h"
+#include <stdlib.h>
 #include "sn_ctx.h"
 
 namespace {
@@ -69,11 +70,14 @@ __global__ __launch_bounds__(256) void sn_apply_head_kernel(const bf16_t* __rest
   for (int i = 0; i < 4; ++i) hbv[i] = hb ? hb[4 * h + i] : 0.f;
   __syncthreads();
 
-  const int64_t p0 = (int64_t)t * PT;
-  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  // PT > 0: the workgroup owns the contiguous pixels [t PT, (t+1) PT); PT == 0: the workgroups of an image interleave
+  // their 64-pixel steps, so the resident ones sweep one compact window of the tensor (DRAM page locality)
+  const int64_t p0 = PT > 0 ? (int64_t)t * PT : (int64_t)t * 64;
+  const int64_t p1 = PT > 0 ? (p0 + PT < HW ? p0 + PT : HW) : HW;
+  const int64_t gstep = PT > 0 ? 64 : (int64_t)gridDim.x * 64;
   const bf16_t* xn = x + (int64_t)n * HW * ldx;
   bf16_t* ln_ = logits + (int64_t)n * HW * 16;
-  for (int64_t g0 = p0 + 16 * wave; g0 < p1; g0 += 64) {
+  for (int64_t g0 = p0 + 16 * wave; g0 < p1; g0 += gstep) {
     const int64_t px = g0 + r;
     const bool ok = px < p1;
     const bf16_t* xp = xn + (ok ? px : p1 - 1) * ldx + 8 * h;
@@ -154,7 +158,7 @@ struct HeadBwdArgs {
   float* hbp;       // pass 1: [N * Tn][16] head bias gradient partials
   bf16_t* dx;       // pass 2
   int64_t ldx, lddx, HW;
-  int N, PT, Tn, relu;
+  int N, PT, Tn, relu, il;
 };
 
 template <int C, bool APPLY>
@@ -171,12 +175,22 @@ __global__ __launch_bounds__(HeadGeom<C>::THREADS, APPLY ? 4 : 3) void sn_head_b
   const int tq = (lane >> 2) & 3, tp = lane & 3;     // transposing read: lane addresses pixel 4g + tq, elements 4tp ..
   const int c0 = 64 * s + 8 * oct;
 
-  // this wave's pixels: the block's tile cut into PG runs of whole 16-pixel steps
-  const int64_t b0 = (int64_t)t * a.PT;
-  const int64_t b1 = b0 + a.PT < a.HW ? b0 + a.PT : a.HW;
-  const int64_t per = ((b1 - b0 + G::PG * 16 - 1) / (G::PG * 16)) * 16;
-  const int64_t p0 = b0 + pg * per;
-  const int64_t p1 = p0 + per < b1 ? p0 + per : b1;
+  // this wave's pixels.  il == 0: the block's tile cut into PG runs of whole 16-pixel steps.  il != 0: the 16-pixel
+  // steps of the image are dealt round-robin to the (block, pixel group) pairs, so the resident blocks sweep one
+  // compact window of each tensor (DRAM page locality) instead of far-apart runs
+  int64_t p0, p1, qstep;
+  if (a.il) {
+    p0 = ((int64_t)t * G::PG + pg) * 16;
+    p1 = a.HW;
+    qstep = (int64_t)gridDim.x * G::PG * 16;
+  } else {
+    const int64_t b0 = (int64_t)t * a.PT;
+    const int64_t b1 = b0 + a.PT < a.HW ? b0 + a.PT : a.HW;
+    const int64_t per = ((b1 - b0 + G::PG * 16 - 1) / (G::PG * 16)) * 16;
+    p0 = b0 + pg * per;
+    p1 = p0 + per < b1 ? p0 + per : b1;
+    qstep = 16;
+  }
 
   const CtxOff o = ctx_off(a.N, C);
   float mu[8], sc[8], be[8], Bc[8], Kc[8];
@@ -286,12 +300,12 @@ __global__ __launch_bounds__(HeadGeom<C>::THREADS, APPLY ? 4 : 3) void sn_head_b
     uint4 xa[2], xb[2];
     uint2 da, db;
     load_step(p0, xa, da);
-    for (int64_t q0 = p0; q0 < p1; q0 += 32) {
-      load_step(q0 + 16, xb, db);
+    for (int64_t q0 = p0; q0 < p1; q0 += 2 * qstep) {
+      load_step(q0 + qstep, xb, db);
       compute_step(q0, xa, da);
-      if (q0 + 16 >= p1) break;                       // wave-uniform
-      load_step(q0 + 32, xa, da);
-      compute_step(q0 + 16, xb, db);
+      if (q0 + qstep >= p1) break;                    // wave-uniform
+      load_step(q0 + 2 * qstep, xa, da);
+      compute_step(q0 + qstep, xb, db);
     }
   }
   if (APPLY) return;
@@ -370,6 +384,11 @@ int head_geometry_ok(int C, int ncls, const char* fn) {
 // Pixels per workgroup of the backward passes (measured at 16 x 512 x 512 x 320: many short workgroups stream better
 // than one round of long ones; pass 1 pays for its partial-sum rows, so its runs are longer).
 static int head_bwd_pt(int apply) { return apply ? 512 : 2048; }
+// SNWS_SN_INTERLEAVE = 0: contiguous pixel runs per workgroup instead of interleaved steps (A/B measurements)
+static bool head_interleave() {
+  static const bool on = !(getenv("SNWS_SN_INTERLEAVE") && atoi(getenv("SNWS_SN_INTERLEAVE")) == 0);
+  return on;
+}
 
 // pixel tiles per image: forward workgroups, or (backward = 1) the partial-sum rows per image that
 // snws_sn_head_bwd_reduce writes for C channels
@@ -385,7 +404,7 @@ extern "C" int snws_sn_apply_head(const void* x, int64_t ldx, const float* ctx, 
   SNWS_CHECK_ARG(N >= 1 && HW >= 1 && ldx >= C && ldx % 8 == 0, "snws_sn_apply_head: bad sizes");
   SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)head_w & 15) == 0 && ((uintptr_t)logits & 7) == 0,
                  "snws_sn_apply_head: pointers must be 16-byte aligned");
-  const int PT = 2048, T = (int)cdiv64(HW, PT);
+  const int T = (int)cdiv64(HW, 2048), PT = head_interleave() ? 0 : 2048;
   hipStream_t st = (hipStream_t)stream;
   if (C == 320)
     sn_apply_head_kernel<10><<<dim3(T, N), 256, 0, st>>>((const bf16_t*)x, ldx, ctx, beta, (const bf16_t*)head_w, head_b,
@@ -407,7 +426,7 @@ extern "C" int snws_sn_head_bwd_reduce(const void* dlogits, const void* x, int64
   HeadBwdArgs a{};
   a.dl = (const bf16_t*)dlogits; a.x = (const bf16_t*)x; a.ctx = ctx; a.beta = beta; a.hw = (const bf16_t*)head_w;
   a.part = part; a.hwp = hw_part; a.hbp = hb_part;
-  a.ldx = ldx; a.HW = HW; a.N = N; a.PT = head_bwd_pt(0); a.relu = relu;
+  a.ldx = ldx; a.HW = HW; a.N = N; a.PT = head_bwd_pt(0); a.relu = relu; a.il = head_interleave();
   const int T = (int)cdiv64(HW, a.PT);
   a.Tn = snws_sn_head_tiles(HW, C, 1);
   hipStream_t st = (hipStream_t)stream;
@@ -428,7 +447,7 @@ extern "C" int snws_sn_head_bwd_apply(const void* dlogits, const void* x, int64_
                  "snws_sn_head_bwd_apply: unaligned pointers");
   HeadBwdArgs a{};
   a.dl = (const bf16_t*)dlogits; a.x = (const bf16_t*)x; a.ctx = ctx; a.ctxb = ctxb; a.beta = beta; a.hw = (const bf16_t*)head_w;
-  a.dx = (bf16_t*)dx; a.ldx = ldx; a.lddx = lddx; a.HW = HW; a.N = N; a.PT = head_bwd_pt(1); a.relu = relu;
+  a.dx = (bf16_t*)dx; a.ldx = ldx; a.lddx = lddx; a.HW = HW; a.N = N; a.PT = head_bwd_pt(1); a.relu = relu; a.il = head_interleave();
   const int T = (int)cdiv64(HW, a.PT);
   hipStream_t st = (hipStream_t)stream;
   if (C == 320) sn_head_bwd_kernel<320, true><<<dim3(T, N), HeadGeom<320>::THREADS, 0, st>>>(a);
