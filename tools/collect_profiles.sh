@@ -12,6 +12,9 @@ cd $R
 bash tools/run_pmc_bench.sh > $out/pmc.log 2>&1
 cp gpurun_out/pmc_bench/summary.json $out/pmc_bench_conv.json
 cp gpurun_out/pmc_bench/all_kernels.json $out/pmc_bench_all_kernels.json
+# bench.py takes roofline.traffic from profiles/<tag>_pmc_bench_conv.json when its source hash matches the tree: put the
+# fresh summary there (in this run's copy of the tree) before the bench lines are taken
+cp $out/pmc_bench_conv.json profiles/${tag}_pmc_bench_conv.json
 timeout -k 10 200 python bench.py > $out/bench_gpus1.json 2> $out/bench_gpus1.err
 timeout -k 10 200 python bench.py --no-cpu-baseline --model unet3p_res_ocr > $out/bench_res_ocr_gpus1.json 2> $out/bench_res_ocr.err
 timeout -k 10 200 python bench.py --no-cpu-baseline --dtype f32 > $out/bench_f32_gpus1.json 2> $out/bench_f32.err
