@@ -124,9 +124,19 @@ __global__ __launch_bounds__(512) void sn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
   double S = 0, Q = 0;
   if (c < C) {
-    // four independent loads in flight per thread (the loop is latency-bound: 16 workgroups read the whole buffer)
+    // eight, then four independent loads in flight per thread (the loop is latency-bound: 16 workgroups read the
+    // whole buffer); the order of the additions is fixed by T alone
     const float2* p = reinterpret_cast<const float2*>(part) + ((int64_t)n * T) * C + c;
     int t = tl;
+    for (; t + 56 < T; t += 64) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(t + 8 * u) * C];
+      S += (((double)v[0].x + (double)v[1].x) + ((double)v[2].x + (double)v[3].x)) +
+           (((double)v[4].x + (double)v[5].x) + ((double)v[6].x + (double)v[7].x));
+      Q += (((double)v[0].y + (double)v[1].y) + ((double)v[2].y + (double)v[3].y)) +
+           (((double)v[4].y + (double)v[5].y) + ((double)v[6].y + (double)v[7].y));
+    }
     for (; t + 24 < T; t += 32) {
       const float2 v0 = p[(int64_t)t * C], v1 = p[(int64_t)(t + 8) * C], v2 = p[(int64_t)(t + 16) * C],
                    v3 = p[(int64_t)(t + 24) * C];
@@ -458,7 +468,16 @@ __global__ __launch_bounds__(512) void sn_bwd_mix_a1_kernel(const float* __restr
   if (c < C) {
     const float2* p = reinterpret_cast<const float2*>(part) + ((int64_t)n * T) * C + c;
     int t = tl;
-    for (; t + 24 < T; t += 32) {       // four independent loads in flight per thread
+    for (; t + 56 < T; t += 64) {       // eight, then four independent loads in flight per thread
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(t + 8 * u) * C];
+      P += (((double)v[0].x + (double)v[1].x) + ((double)v[2].x + (double)v[3].x)) +
+           (((double)v[4].x + (double)v[5].x) + ((double)v[6].x + (double)v[7].x));
+      Q += (((double)v[0].y + (double)v[1].y) + ((double)v[2].y + (double)v[3].y)) +
+           (((double)v[4].y + (double)v[5].y) + ((double)v[6].y + (double)v[7].y));
+    }
+    for (; t + 24 < T; t += 32) {
       const float2 v0 = p[(int64_t)t * C], v1 = p[(int64_t)(t + 8) * C], v2 = p[(int64_t)(t + 16) * C],
                    v3 = p[(int64_t)(t + 24) * C];
       P += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
