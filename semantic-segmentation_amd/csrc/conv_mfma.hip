@@ -57,12 +57,8 @@ __device__ unsigned long long snws_dbg[8];
 // priorities two waves that multiply at the same time share the matrix pipe evenly, finish together and then stage
 // together - the pipe idles for a whole staging latency.  A wave that is further into its matrix phase outranks one
 // that has just begun, so the leader finishes at full speed (first come, first served) and the pair falls into
-// alternation.  level: 0 outside the matrix phase, 1..3 by progress.
-template <int LEVEL>
-__device__ __forceinline__ void prio_step(int on) {
-  if (on) __builtin_amdgcn_s_setprio(LEVEL);
-}
-
+// alternation.  level: 0 outside the matrix phase, 1..3 by progress.  The levels are set at compile-time positions of
+// the unrolled matrix phase (template parameter PRIO; a run-time test there costs more than the priority gains).
 // XCD-aware block id: blocks that are dealt to the same XCD (bid % 8) get consecutive logical ids, so tiles that
 // share an input patch or a filter slab also share an L2.  Bijective for any grid size.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
@@ -93,7 +89,7 @@ struct FwdArgs {
   int64_t ldx, ldy;
   int tilesX, tilesY, coTiles, nchunks;
   int accumulate;     // != 0: y += result (a gradient with several contributors: a later contributor adds in place)
-  int prio;           // != 0: the wave priority rises as a chunk's matrix work progresses (see prio_step)
+  int prio;           // host side only: which PRIO instantiation to launch
 };
 // arguments of the dgrad variant whose epilogue also reduces for the SwitchNorm layers behind its output
 struct FwdArgsBwr : FwdArgs {
@@ -136,7 +132,7 @@ __device__ __forceinline__ int col_swz(int px) {
 // M16      : v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (KC = 32 only).  Same FLOPs per cycle and the same LDS
 //             bytes per FLOP, but the chip holds a higher clock under this shape.
 // BWR      : the dgrad + SwitchNorm-backward-reduction variant (its own kernel, so a profile lists it separately).
-template <int KC, int TAPS, bool DB, bool M16, bool BWR = false>
+template <int KC, int TAPS, bool DB, bool M16, bool BWR = false, int PRIO = 0>
 __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kernel(
     std::conditional_t<BWR, FwdArgsBwr, FwdArgs> a) {
   static_assert(!M16 || KC == 32, "the 16x16x32 shape contracts 32 channels per instruction");
@@ -287,9 +283,12 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
       const int kw = st / NR, rho = st % NR;
-      if (st == 0) prio_step<1>(a.prio);
-      if (st == NSTEP / 3) prio_step<2>(a.prio);
-      if (st == 2 * NSTEP / 3) prio_step<3>(a.prio);
+      // (compile-time: a branch here would cut the unrolled walk into blocks)
+      if constexpr (PRIO == 1) {
+        if (st == 0) __builtin_amdgcn_s_setprio(1);
+        if (st == NSTEP / 3) __builtin_amdgcn_s_setprio(2);
+        if (st == 2 * NSTEP / 3) __builtin_amdgcn_s_setprio(3);
+      }
       if (st + 1 < NSTEP) load_b(st + 1);
       if (rho + 1 < KHN) load_a(kw, rho + 1);                 // first used by the next row
       if (rho == NR - 1 && kw + 1 < KWN) load_a(kw + 1, 0);   // kh = 0 of this kw was last used at row 3
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(256, (DB && TAPS == 9) ? 1 : 2) void conv_fwd_kerne
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    prio_step<0>(a.prio);
+    if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
   };
   auto compute = [&](int so) {
     if constexpr (M16) compute16(so); else compute32(so);
@@ -609,7 +608,7 @@ struct WgradArgs {
   int N, H, W, Cin, Cout;   // Cin: channels of x that take part (multiple of 16); dw rows have Cin entries
   int64_t ldx, lddy;
   int tilesX, tilesY, coTiles, ciTiles, tilesPerSplit;
-  int prio;                 // != 0: the wave priority rises as a tile's matrix work progresses (see prio_step)
+  int prio;                 // host side only: which PRIO instantiation to launch
 };
 
 constexpr int WG_TH = 8, WG_TW = 32;
@@ -1618,14 +1617,14 @@ int conv_db_mode() {
   return mode;
 }
 
-template <int KC, int TAPS, bool DB, bool M16, bool BWR>
+template <int KC, int TAPS, bool DB, bool M16, bool BWR, int PRIO = 0>
 int launch_fwd_v(const std::conditional_t<BWR, FwdArgsBwr, FwdArgs>& a, unsigned grid, hipStream_t st) {
   using G = FwdGeom<KC, TAPS>;
   constexpr int LDS = DB ? G::LDS_BYTES_DB : G::LDS_BYTES;
   static PerDeviceOnce once;
   std::atomic<bool>* const attr_set = once.flag();
   if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<KC, TAPS, DB, M16, BWR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<KC, TAPS, DB, M16, BWR, PRIO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1633,7 +1632,7 @@ int launch_fwd_v(const std::conditional_t<BWR, FwdArgsBwr, FwdArgs>& a, unsigned
     }
     if (attr_set) attr_set->store(true, std::memory_order_release);
   }
-  conv_fwd_kernel<KC, TAPS, DB, M16, BWR><<<grid, 256, LDS, st>>>(a);
+  conv_fwd_kernel<KC, TAPS, DB, M16, BWR, PRIO><<<grid, 256, LDS, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_fwd");
   return SNWS_OK;
 }
@@ -1648,6 +1647,7 @@ int launch_fwd(const std::conditional_t<BWR, FwdArgsBwr, FwdArgs>& a, unsigned g
     static const int m16_env = getenv("SNWS_CONV_M16") ? atoi(getenv("SNWS_CONV_M16")) : -1;
     const bool m16 = m16_env >= 0 ? m16_env != 0 : true;   // +13% over 32x32x16 at equal cycles (higher sustained clock)
     if (db) return m16 ? launch_fwd_v<32, TAPS, true, true, BWR>(a, grid, st) : launch_fwd_v<32, TAPS, true, false, BWR>(a, grid, st);
+    if (m16 && TAPS == 9 && a.prio == 1) return launch_fwd_v<32, TAPS, false, true, BWR, (TAPS == 9 ? 1 : 0)>(a, grid, st);
     return m16 ? launch_fwd_v<32, TAPS, false, true, BWR>(a, grid, st) : launch_fwd_v<32, TAPS, false, false, BWR>(a, grid, st);
   } else {
     return launch_fwd_v<KC, TAPS, false, false, BWR>(a, grid, st);
