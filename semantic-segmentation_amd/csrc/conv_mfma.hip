@@ -46,7 +46,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 
 #ifdef SNWS_TIMING
 // Diagnostics build (-DSNWS_TIMING): shader-clock cycles the forward kernel's workgroups spend waiting for staged data,
-// in the matrix phase and in the epilogue, summed over workgroups (wave 0 only); snws_dbg_read copies and clears them.
+// in the matrix phase and in the epilogue ([0..3]), and the 3x3 wgrad's per pixel tile waiting / multiplying ([4..7]),
+// summed over workgroups (wave 0 only); snws_dbg_read copies and clears them.
 __device__ unsigned long long snws_dbg[8];
 #define SNWS_T(var) const long long var = clock64()
 #else
@@ -1306,7 +1307,13 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   const unsigned st_dy_off = (unsigned)(((wave * 8 + st_q) * a.lddy + st_chunk * 8) * 2);
   const int st_px0 = wave * 8 + st_q;                                  // halo pixel 8*wave + q lies in halo row 0
   const unsigned st_x_off = (unsigned)((st_px0 * a.ldx + st_chunk * 8) * 2);
+#ifdef SNWS_TIMING
+  long long dbg_wait = 0, dbg_comp = 0;
+#endif
   for (int t = t_begin; t < t_end; ++t) {
+#ifdef SNWS_TIMING
+    const long long dbg_ta = clock64();
+#endif
     int tt = t;
     const int tx = tt % a.tilesX; tt /= a.tilesX;
     const int ty = tt % a.tilesY;
@@ -1372,6 +1379,10 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef SNWS_TIMING
+    const long long dbg_tb = clock64();
+    dbg_wait += dbg_tb - dbg_ta;
+#endif
 
     if (want_bias) {  // bias gradient: column sums of the dy tile, kept per wave in LDS (block-uniform branch)
       const int c8 = tid & 7;
@@ -1504,7 +1515,18 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
     }
     }
     __syncthreads();
+#ifdef SNWS_TIMING
+    dbg_comp += clock64() - dbg_tb;
+#endif
   }
+#ifdef SNWS_TIMING
+  if (tid == 0) {
+    atomicAdd(&snws_dbg[4], (unsigned long long)dbg_wait);
+    atomicAdd(&snws_dbg[5], (unsigned long long)dbg_comp);
+    atomicAdd(&snws_dbg[6], (unsigned long long)(t_end - t_begin));
+    atomicAdd(&snws_dbg[7], 1ull);
+  }
+#endif
 
   // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
   if constexpr (M16) {
