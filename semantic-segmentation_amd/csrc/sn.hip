@@ -41,15 +41,37 @@ inline int sn_tiles(int N, int64_t HW, int C) {
   return (int)cdiv64(HW, PT);
 }
 
+// V consecutive per-channel coefficients: 16-byte loads when the address allows (a workgroup's first data loads wait
+// behind these, so their count is the start-up latency of every workgroup of the streaming passes)
+template <int V>
+__device__ __forceinline__ void load_coef(const float* __restrict__ p, float (&out)[V]) {
+  if constexpr (V % 4 == 0) {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < V / 4; ++k) {
+        const float4 q = reinterpret_cast<const float4*>(p)[k];
+        out[4 * k] = q.x; out[4 * k + 1] = q.y; out[4 * k + 2] = q.z; out[4 * k + 3] = q.w;
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) out[v] = p[v];
+}
+
 // ------------------------------------------------------------------------------------------- pass 1: moments
 template <typename T, int V>
 __global__ __launch_bounds__(SN_THREADS) void sn_stats_kernel(const T* __restrict__ x, int64_t HW, int C, int64_t ldx,
                                                               int PT, int Tn, SnMap m, float* __restrict__ part,
                                                               float* __restrict__ shift_out) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][PR][cgb*V]
+  // PT == 0: the workgroups of an image interleave pieces of 4 PR pixels (see sn_apply_kernel); a partial-sum row then
+  // belongs to a strided set of pixels instead of a contiguous range - its consumers only ever sum the rows
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const int64_t p0 = (int64_t)t * PT;
-  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  const int64_t PS = 4 * (int64_t)m.PR;
+  const int64_t p0 = PT > 0 ? (int64_t)t * PT : (int64_t)t * PS;
+  const int64_t p1 = PT > 0 ? (p0 + PT < HW ? p0 + PT : HW) : HW;
+  const int64_t pstep = PT > 0 ? PS : (int64_t)gridDim.x * PS;
   const T* xn = x + (int64_t)n * HW * ldx;
   const int cgl = tid % m.cgb, prow = tid / m.cgb;
   const int row = m.cgb * V;
@@ -66,7 +88,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_stats_kernel(const T* __restric
         for (int v = 0; v < V; ++v) shift_out[(int64_t)n * C + cg * V + v] = sh[v];
       }
       int64_t p = p0 + prow;
-      for (; p + 3 * m.PR < p1; p += 4 * m.PR) {
+      for (; p + 3 * m.PR < p1; p += pstep) {
         float a[V], b[V], c[V], d[V];
         Vec<T, V>::load(xn + p * ldx + (int64_t)cg * V, a);
         Vec<T, V>::load(xn + (p + m.PR) * ldx + (int64_t)cg * V, b);
@@ -256,24 +278,6 @@ __global__ __launch_bounds__(256) void sn_mix_b_kernel(float* __restrict__ ctx, 
   ctx[o.scale + i] = gamma[c] * rstd;
 }
 
-// V consecutive per-channel coefficients: 16-byte loads when the address allows (a workgroup's first data loads wait
-// behind these, so their count is the start-up latency of every workgroup of the streaming passes)
-template <int V>
-__device__ __forceinline__ void load_coef(const float* __restrict__ p, float (&out)[V]) {
-  if constexpr (V % 4 == 0) {
-    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-#pragma unroll
-      for (int k = 0; k < V / 4; ++k) {
-        const float4 q = reinterpret_cast<const float4*>(p)[k];
-        out[4 * k] = q.x; out[4 * k + 1] = q.y; out[4 * k + 2] = q.z; out[4 * k + 3] = q.w;
-      }
-      return;
-    }
-  }
-#pragma unroll
-  for (int v = 0; v < V; ++v) out[v] = p[v];
-}
-
 // ------------------------------------------------------------------------------------------- pass 2: normalise
 template <typename T, int V, bool RELU, bool RES>
 __global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
@@ -364,9 +368,13 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_reduce_kernel(const T* __re
                                                                    int C, int PT, int Tn, SnMap m,
                                                                    float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float red[];
+  // PT == 0: interleaved pieces of U PR pixels (see sn_stats_kernel)
+  constexpr int U = SN_BWD_ROWS<YMASK>;
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const int64_t p0 = (int64_t)t * PT;
-  const int64_t p1 = p0 + PT < HW ? p0 + PT : HW;
+  const int64_t PS = U * (int64_t)m.PR;
+  const int64_t p0 = PT > 0 ? (int64_t)t * PT : (int64_t)t * PS;
+  const int64_t p1 = PT > 0 ? (p0 + PT < HW ? p0 + PT : HW) : HW;
+  const int64_t pstep = PT > 0 ? PS : (int64_t)gridDim.x * PS;
   const CtxOff o = ctx_off(N, C);
   const T* xn = x + (int64_t)n * HW * ldx;
   const T* dn = dy + (int64_t)n * HW * lddy;
@@ -381,37 +389,38 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_reduce_kernel(const T* __re
     for (int v = 0; v < V; ++v) P[v] = Q[v] = 0.f;
     if (valid) {
       float mu[V], sc[V], rs[V], be[V];
-#pragma unroll
-      for (int v = 0; v < V; ++v) {
-        const int64_t i = (int64_t)n * C + cg * V + v;
-        mu[v] = ctx[o.mean + i];
-        sc[v] = ctx[o.scale + i];
-        rs[v] = ctx[o.rstd + i];
-        be[v] = beta[cg * V + v];
+      {
+        const int64_t i0 = (int64_t)n * C + cg * V;
+        load_coef<V>(ctx + o.mean + i0, mu);
+        load_coef<V>(ctx + o.scale + i0, sc);
+        load_coef<V>(ctx + o.rstd + i0, rs);
+        load_coef<V>(beta + cg * V, be);
       }
       const int64_t co = (int64_t)cg * V;
       int64_t p = p0 + prow;
-      for (; p + m.PR < p1; p += 2 * m.PR) {
-        float a0[V], a1[V], g0[V], g1[V], y0[V], y1[V];
-        VecNT<T, V>::load(xn + p * ldx + co, a0);
-        VecNT<T, V>::load(xn + (p + m.PR) * ldx + co, a1);
-        VecNT<T, V>::load(dn + p * lddy + co, g0);
-        VecNT<T, V>::load(dn + (p + m.PR) * lddy + co, g1);
+      for (; p + (U - 1) * m.PR < p1; p += pstep) {
+        float a[U][V], g[U][V], yv[YMASK ? U : 1][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) VecNT<T, V>::load(xn + (p + u * m.PR) * ldx + co, a[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) VecNT<T, V>::load(dn + (p + u * m.PR) * lddy + co, g[u]);
         if (YMASK) {
-          VecNT<T, V>::load(yn + p * ldy + co, y0);
-          VecNT<T, V>::load(yn + (p + m.PR) * ldy + co, y1);
+#pragma unroll
+          for (int u = 0; u < U; ++u) VecNT<T, V>::load(yn + (p + u * m.PR) * ldy + co, yv[YMASK ? u : 0]);
         }
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          float e0 = a0[v] - mu[v], e1 = a1[v] - mu[v];
-          if (RELU) {
-            bool k0 = YMASK ? (y0[v] > 0.f) : (fmaf(e0, sc[v], be[v]) > 0.f);
-            bool k1 = YMASK ? (y1[v] > 0.f) : (fmaf(e1, sc[v], be[v]) > 0.f);
-            g0[v] = k0 ? g0[v] : 0.f;
-            g1[v] = k1 ? g1[v] : 0.f;
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const float e = a[u][v] - mu[v];
+            float gg = g[u][v];
+            if (RELU) {
+              const bool k = YMASK ? (yv[YMASK ? u : 0][v] > 0.f) : (fmaf(e, sc[v], be[v]) > 0.f);
+              gg = k ? gg : 0.f;
+            }
+            P[v] += gg;
+            Q[v] += gg * (e * rs[v]);
           }
-          P[v] += g0[v] + g1[v];
-          Q[v] += g0[v] * (e0 * rs[v]) + g1[v] * (e1 * rs[v]);
         }
       }
       for (; p < p1; p += m.PR) {
@@ -779,23 +788,23 @@ bool can_vec(int C, std::initializer_list<const void*> ptrs, std::initializer_li
                  (long long)HW);                                                                   \
   SNWS_CHECK_ARG(dtype == SNWS_F32 || dtype == SNWS_BF16, fn ": dtype %d is not F32/BF16", dtype);
 
-template <typename T, int V>
-int run_stats(const void* x, int N, int64_t HW, int C, int64_t ldx, float* part, float* shift, hipStream_t st) {
-  const SnMap m = sn_map(C, V);
-  const int T_ = sn_tiles(N, HW, C);
-  const int PT = (int)cdiv64(HW, T_);
-  const size_t lds = (size_t)2 * m.PR * m.cgb * V * sizeof(float);
-  sn_stats_kernel<T, V><<<dim3(T_, N), SN_THREADS, lds, st>>>((const T*)x, HW, C, ldx, PT, T_, m, part, shift);
-  SNWS_LAUNCH_CHECK("snws_sn_stats");
-  return SNWS_OK;
-}
-
 // SNWS_SN_INTERLEAVE = 0 gives every workgroup of the apply passes one contiguous pixel range instead of interleaved
 // pieces (A/B measurements)
 inline bool sn_interleave() {
   static const bool on = !(getenv("SNWS_SN_INTERLEAVE") && atoi(getenv("SNWS_SN_INTERLEAVE")) == 0);
   return on;
 }
+template <typename T, int V>
+int run_stats(const void* x, int N, int64_t HW, int C, int64_t ldx, float* part, float* shift, hipStream_t st) {
+  const SnMap m = sn_map(C, V);
+  const int T_ = sn_tiles(N, HW, C);        // = the partial-sum rows per image the caller allocated
+  const int PT = sn_interleave() ? 0 : (int)cdiv64(HW, T_);
+  const size_t lds = (size_t)2 * m.PR * m.cgb * V * sizeof(float);
+  sn_stats_kernel<T, V><<<dim3(T_, N), SN_THREADS, lds, st>>>((const T*)x, HW, C, ldx, PT, T_, m, part, shift);
+  SNWS_LAUNCH_CHECK("snws_sn_stats");
+  return SNWS_OK;
+}
+
 // grid of an apply pass whose workgroups interleave pieces of `piece` pixels: the workgroup count of the contiguous
 // walk (64 KB of a tensor per workgroup, at most 4096 workgroups: shorter workgroups spend their time loading
 // coefficients), never more than there are pieces
@@ -825,8 +834,8 @@ int run_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, con
                    const float* ctx, const float* beta, int N, int64_t HW, int C, int relu, float* part,
                    hipStream_t st) {
   const SnMap m = sn_map(C, V);
-  const int T_ = sn_tiles(N, HW, C);
-  const int PT = (int)cdiv64(HW, T_);
+  const int T_ = sn_tiles(N, HW, C);        // = the partial-sum rows per image the caller allocated
+  const int PT = sn_interleave() ? 0 : (int)cdiv64(HW, T_);
   const size_t lds = (size_t)2 * m.PR * m.cgb * V * sizeof(float);
   dim3 grid(T_, N);
 #define BR(R, Y) sn_bwd_reduce_kernel<T, V, R, Y><<<grid, SN_THREADS, lds, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)ym, ldy, ctx, beta, N, HW, C, PT, T_, m, part)
