@@ -15,6 +15,7 @@
 //     (summed afterwards in a fixed order: bit-reproducible).
 // The soft-max runs in float32 on the accumulators; probabilities enter the second product rounded to bf16.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -163,13 +164,28 @@ __device__ __forceinline__ float xg_sum(float v) {
 
 constexpr int OCR_WAVES = 4, OCR_THREADS = 64 * OCR_WAVES;
 
-// this wave's run of whole 16-pixel steps inside the workgroup's pixel tile
-__device__ __forceinline__ void wave_run(int t, int PT, int64_t HW, int wave, int64_t& p0, int64_t& p1) {
+// this wave's 16-pixel steps: first pixel p0, end p1, distance qs between consecutive steps.  il == 0: a contiguous run
+// inside the workgroup's pixel tile.  il != 0: the 16-pixel steps of the image are dealt round-robin to the (workgroup,
+// wave) pairs, so the resident workgroups sweep one compact window of each tensor instead of far-apart runs (DRAM
+// page locality); per-workgroup partial results then belong to a strided pixel set - their consumers only sum them.
+__device__ __forceinline__ void wave_run(int t, int PT, int64_t HW, int wave, int il, int64_t& p0, int64_t& p1, int64_t& qs) {
+  if (il) {
+    p0 = ((int64_t)t * OCR_WAVES + wave) * 16;
+    p1 = HW;
+    qs = (int64_t)gridDim.x * OCR_WAVES * 16;
+    return;
+  }
   const int64_t b0 = (int64_t)t * PT;
   const int64_t b1 = b0 + PT < HW ? b0 + PT : HW;
   const int64_t per = ((b1 - b0 + OCR_WAVES * 16 - 1) / (OCR_WAVES * 16)) * 16;
   p0 = b0 + wave * per;
   p1 = p0 + per < b1 ? p0 + per : b1;
+  qs = 16;
+}
+// SNWS_SN_INTERLEAVE = 0: contiguous runs (A/B measurements)
+inline int ocr_interleave() {
+  static const int on = !(getenv("SNWS_SN_INTERLEAVE") && atoi(getenv("SNWS_SN_INTERLEAVE")) == 0);
+  return on;
 }
 
 // ------------------------------------------------------------------------------------------------ object attention
@@ -182,7 +198,7 @@ struct AttnArgs {
   float* dkey_part;     // backward: [B][Tn][16][C]
   float* dval_part;
   int64_t ldq, lddo, ldo, HW;
-  int K, PT, Tn;
+  int K, PT, Tn, il;
   float scale;
 };
 
@@ -226,15 +242,15 @@ __global__ __launch_bounds__(OCR_THREADS) void ocr_attend_fwd_kernel(AttnArgs a)
 #pragma unroll
   for (int cb = 0; cb < C / 16; ++cb) vT[cb] = T::tr(val_t, L, cb);
 
-  int64_t p0, p1;
-  wave_run(t, a.PT, a.HW, wave, p0, p1);
+  int64_t p0, p1, qs;
+  wave_run(t, a.PT, a.HW, wave, a.il, p0, p1, qs);
   const bf16_t* qi = a.q + (int64_t)b * a.HW * a.ldq;
   bf16_t* oi = a.out + (int64_t)b * a.HW * a.ldo;
   if (p0 >= p1) return;
   typename T::vec_t v = T::load_vec(qi, a.ldq, p0, p1, L);
-  for (int64_t q0 = p0; q0 < p1; q0 += 16) {
+  for (int64_t q0 = p0; q0 < p1; q0 += qs) {
     T::stash_vec(tile, L, v);
-    v = T::load_vec(qi, a.ldq, q0 + 16, p1, L);  // the next step's pixels, in flight while this step computes (clamped past the run)
+    v = T::load_vec(qi, a.ldq, q0 + qs, p1, L);  // the next step's pixels, in flight while this step computes (clamped past the run)
     wave_lds_sync();
     f32x4 S = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -274,12 +290,12 @@ __global__ __launch_bounds__(OCR_THREADS) void ocr_attend_bwd_kernel(AttnArgs a)
 #pragma unroll
   for (int cb = 0; cb < C / 16; ++cb) dV[cb] = dK[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int64_t p0, p1;
-  wave_run(t, a.PT, a.HW, wave, p0, p1);
+  int64_t p0, p1, qs;
+  wave_run(t, a.PT, a.HW, wave, a.il, p0, p1, qs);
   const bf16_t* qi = a.q + (int64_t)b * a.HW * a.ldq;
   const bf16_t* di = a.dout + (int64_t)b * a.HW * a.lddo;
   bf16_t* oi = a.out + (int64_t)b * a.HW * a.ldo;
-  for (int64_t q0 = p0; q0 < p1; q0 += 16) {
+  for (int64_t q0 = p0; q0 < p1; q0 += qs) {
     {
       uint4 v[T::NV], w[T::NV];
       T::load(qi, a.ldq, q0, p1, L, v);
@@ -407,7 +423,7 @@ struct GatherArgs {
   bf16_t* dfeats;         // backward: [B][HW][lddf]
   bf16_t* dprobs;         // backward: [B][HW][16]
   int64_t ldf, ldp, lddf, HW;
-  int K, PT, Tn, Ts;
+  int K, PT, Tn, Ts, il;
   float scale;
   int accumulate;         // backward: dfeats += (it holds the other consumers' shares of the gradient)
 };
@@ -440,11 +456,11 @@ __global__ __launch_bounds__(OCR_THREADS) void ocr_gather_fwd_kernel(GatherArgs 
   f32x4 acc[C / 16];
 #pragma unroll
   for (int cb = 0; cb < C / 16; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int64_t p0, p1;
-  wave_run(t, a.PT, a.HW, wave, p0, p1);
+  int64_t p0, p1, qs;
+  wave_run(t, a.PT, a.HW, wave, a.il, p0, p1, qs);
   const bf16_t* fi = a.feats + (int64_t)b * a.HW * a.ldf;
   const bf16_t* pi = a.probs + (int64_t)b * a.HW * a.ldp;
-  for (int64_t q0 = p0; q0 < p1; q0 += 16) {
+  for (int64_t q0 = p0; q0 < p1; q0 += qs) {
     {
       uint4 v[T::NV];
       T::load(fi, a.ldf, q0, p1, L, v);
@@ -481,13 +497,13 @@ __global__ __launch_bounds__(OCR_THREADS) void ocr_gather_bwd_kernel(GatherArgs 
   if (threadIdx.x < 16) dots[threadIdx.x] = a.dot[b * 16 + threadIdx.x];
   T::fill(dctx_t, a.dctx + (int64_t)b * 16 * C);
   __syncthreads();
-  int64_t p0, p1;
-  wave_run(t, a.PT, a.HW, wave, p0, p1);
+  int64_t p0, p1, qs;
+  wave_run(t, a.PT, a.HW, wave, a.il, p0, p1, qs);
   const bf16_t* fi = a.feats + (int64_t)b * a.HW * a.ldf;
   const bf16_t* pi = a.probs + (int64_t)b * a.HW * a.ldp;
   bf16_t* dfi = a.dfeats + (int64_t)b * a.HW * a.lddf;
   bf16_t* dpi = a.dprobs + (int64_t)b * a.HW * 16;
-  for (int64_t q0 = p0; q0 < p1; q0 += 16) {
+  for (int64_t q0 = p0; q0 < p1; q0 += qs) {
     {
       uint4 v[T::NV];
       T::load(fi, a.ldf, q0, p1, L, v);
@@ -556,7 +572,7 @@ extern "C" int snws_ocr_attend_fwd(const void* q, int64_t ldq, const void* key, 
   if (int rc = set_lds(&ocr_attend_fwd_kernel<ATTN_C>, LDS, "snws_ocr_attend_fwd", once)) return rc;
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.key = (const bf16_t*)key; a.val = (const bf16_t*)val; a.out = (bf16_t*)out;
-  a.ldq = ldq; a.ldo = ldo; a.HW = HW; a.K = K; a.PT = ATTN_PT; a.scale = scale;
+  a.ldq = ldq; a.ldo = ldo; a.HW = HW; a.K = K; a.PT = ATTN_PT; a.scale = scale; a.il = ocr_interleave();
   ocr_attend_fwd_kernel<ATTN_C><<<dim3((unsigned)cdiv64(HW, ATTN_PT), B), OCR_THREADS, LDS, (hipStream_t)stream>>>(a);
   SNWS_LAUNCH_CHECK("snws_ocr_attend_fwd");
   return SNWS_OK;
@@ -578,7 +594,7 @@ extern "C" int snws_ocr_attend_bwd(const void* q, int64_t ldq, const void* dout,
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.dout = (const bf16_t*)dout; a.key = (const bf16_t*)key; a.val = (const bf16_t*)val; a.out = (bf16_t*)dq;
   a.dkey_part = dkey_part; a.dval_part = dval_part;
-  a.ldq = ldq; a.lddo = lddo; a.ldo = lddq; a.HW = HW; a.K = K; a.PT = ATTN_PT; a.Tn = snws_ocr_tiles(HW, 2); a.scale = scale;
+  a.ldq = ldq; a.lddo = lddo; a.ldo = lddq; a.HW = HW; a.K = K; a.PT = ATTN_PT; a.Tn = snws_ocr_tiles(HW, 2); a.scale = scale; a.il = ocr_interleave();
   ocr_attend_bwd_kernel<ATTN_C><<<dim3((unsigned)cdiv64(HW, ATTN_PT), B), OCR_THREADS, LDS, (hipStream_t)stream>>>(a);
   SNWS_LAUNCH_CHECK("snws_ocr_attend_bwd");
   return SNWS_OK;
@@ -608,7 +624,7 @@ extern "C" int snws_ocr_gather_fwd(const void* feats, int64_t ldf, const void* p
   if (int rc = set_lds(&ocr_gather_fwd_kernel<GATHER_C>, LDS, "snws_ocr_gather_fwd", once)) return rc;
   GatherArgs a{};
   a.feats = (const bf16_t*)feats; a.probs = (const bf16_t*)probs; a.stat_part = stat_part; a.ctx_part = ctx_part;
-  a.ldf = ldf; a.ldp = ldp; a.HW = HW; a.K = K; a.PT = GATHER_PT; a.Tn = snws_ocr_tiles(HW, 1); a.Ts = snws_ocr_tiles(HW, 0);
+  a.ldf = ldf; a.ldp = ldp; a.HW = HW; a.K = K; a.PT = GATHER_PT; a.Tn = snws_ocr_tiles(HW, 1); a.Ts = snws_ocr_tiles(HW, 0); a.il = ocr_interleave();
   a.scale = scale;
   ocr_gather_fwd_kernel<GATHER_C><<<dim3((unsigned)cdiv64(HW, GATHER_PT), B), OCR_THREADS, LDS, (hipStream_t)stream>>>(a);
   SNWS_LAUNCH_CHECK("snws_ocr_gather_fwd");
@@ -632,7 +648,7 @@ int run_ocr_gather_bwd(const void* feats, int64_t ldf, const void* probs, int64_
   GatherArgs a{};
   a.feats = (const bf16_t*)feats; a.probs = (const bf16_t*)probs; a.stat_part = stat_part; a.dctx = (const bf16_t*)dctx; a.dot = dot;
   a.dfeats = (bf16_t*)dfeats; a.dprobs = (bf16_t*)dprobs;
-  a.ldf = ldf; a.ldp = ldp; a.lddf = lddf; a.HW = HW; a.K = K; a.PT = GATHER_PT; a.Ts = snws_ocr_tiles(HW, 0); a.scale = scale;
+  a.ldf = ldf; a.ldp = ldp; a.lddf = lddf; a.HW = HW; a.K = K; a.PT = GATHER_PT; a.Ts = snws_ocr_tiles(HW, 0); a.scale = scale; a.il = ocr_interleave();
   a.accumulate = accumulate;
   ocr_gather_bwd_kernel<GATHER_C><<<dim3((unsigned)cdiv64(HW, GATHER_PT), B), OCR_THREADS, LDS, (hipStream_t)stream>>>(a);
   SNWS_LAUNCH_CHECK("snws_ocr_gather_bwd");
