@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER, Structure
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsnws.so")
+# SNWS_LIB = <file name inside lib/>: load another in-tree build of the library (same-box A/B runs of two kernel versions)
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", os.path.basename(os.environ.get("SNWS_LIB", "libsnws.so")))
 
 SNWS_F32, SNWS_BF16, SNWS_F64, SNWS_I64, SNWS_I32, SNWS_U8 = 0, 1, 2, 3, 4, 5
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3
