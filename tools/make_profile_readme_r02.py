@@ -63,7 +63,10 @@ out = ["## Round 2", "",
        % (bo["value"], bo["ms_per_step"], "no rocBLAS / hipBLASLt (`Cijk_*`) kernel" if not vendor else "VENDOR GEMM KERNELS PRESENT",
           100.0 * oours / otot),
        "* `r02_mm_ceiling.txt` - what the vendor GEMM and the library's own 3x3 kernels reach with random and with all-zero "
-       "operands (`tools/mm_ceiling.py`): the chip lowers its clock under toggling matrix data.", "",
+       "operands (`tools/mm_ceiling.py`): the chip lowers its clock under toggling matrix data.",
+       "* `r02_pmc_sq_conv_wgrad.txt` - SQ / GRBM counters of the 3x3 forward and weight-gradient kernels on the 320->320 layer "
+       "(`tools/run_pmc.sh conv | wgrad`): matrix pipe busy 75 % / 70 % of the active cycles at an effective clock of 1.72 / 1.74 GHz "
+       "(round 1: 69 % / 61 % at 1.86 / 1.77 GHz), and the counters of the rejected conflict-free LDS swizzle of the wgrad kernel.", "",
        "| kernel | calls | total ms/step | avg us | % |", "|---|---:|---:|---:|---:|"]
 for r in rows[:26]:
     out.append("| `%s` | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], int(r["TotalDurationNs"]) / 5e6,
