@@ -1,6 +1,7 @@
 // Implicit-GEMM 3x3 / 1x1 convolution on the gfx950 bf16 matrix cores (replaces F.conv2d at
 // modeling/weightstd.py:18 of the reference and its autograd for the stride-1 "same" convolutions of the
-// UNet3+ stack).  NHWC bf16 activations, f32 accumulation, v_mfma_f32_32x32x16_bf16.
+// UNet3+ stack).  NHWC bf16 activations, f32 accumulation, v_mfma_f32_16x16x32_bf16 (v_mfma_f32_32x32x16_bf16 forms
+// are kept behind switches for A/B runs).
 //
 // Forward / dgrad (one kernel; dgrad = forward over dy with the flipped, transposed filter image):
 //   workgroup = 4 waves = a 16x32 pixel patch of one image x 64 output channels; wave w owns rows 4w..4w+3.
@@ -10,7 +11,8 @@
 //   every tap reads its shifted B fragments from the SAME halo patch.  Pixels are 16-byte-chunk XOR-swizzled so
 //   the 16 lanes of a ds_read_b128 group hit 16 distinct bank slots; the swizzle is applied to the per-lane
 //   SOURCE address because LDS-DMA writes lane-linearly.  Two workgroups per CU (76.8 KB LDS each) overlap one
-//   block's staging with the other's MFMAs.
+//   block's staging with the other's MFMAs; inside the matrix phase a wave's priority rises with its progress, so
+//   the co-resident pair drifts into alternation instead of multiplying - and then waiting - together.
 //   Epilogue: accumulators (+bias) -> bf16 -> LDS -> 128-byte-per-pixel coalesced stores (issued last: nothing in
 //   the workgroup waits for them), plus optional per-tile sum / sum-of-squares of the ROUNDED outputs per channel,
 //   which SwitchNorm consumes instead of re-reading the tensor.  The BWR instantiation (dgrad only) instead reduces,
@@ -19,9 +21,12 @@
 //
 // Wgrad: D[out channel][in channel] = sum over pixels; both operands are needed pixel-major per lane, so the
 //   NHWC tiles are read from LDS with the transposing ds_read_b64_tr_b16.  A workgroup owns a 64x64 (out,in)
-//   filter tile for all taps (144 accumulator registers per lane), sweeps a slice of the pixel tiles, and adds
-//   its result to the f32 gradient with float atomics (128-byte segments per wave-instruction).  3x3 and 1x1 have
-//   their own kernels (conv_wgrad9_kernel, conv_wgrad1_kernel); the generic one serves C_in = 16.
+//   filter tile for all taps (144 accumulator registers per lane) and sweeps a slice of the pixel tiles; in the 3x3
+//   kernel a wave owns all 64 out channels x a 16-wide in-channel quarter x all nine taps and walks the halo rows, so
+//   one B fragment serves three taps.  The result leaves either as per-workgroup partial tiles that a fixed-order
+//   reduction sums (bit-reproducible; what the host modules use) or by float atomics into the f32 gradient.  3x3
+//   and 1x1 have their own kernels (conv_wgrad9q_kernel / conv_wgrad9_kernel, conv_wgrad1*_kernel); the generic one
+//   serves C_in = 16.
 #include "common.h"
 #include "pack.h"
 #include "wgrad_reduce.h"
