@@ -1,0 +1,67 @@
+"""Helper of test_gpu_ab_switches.py (not a test module): runs a fixed, seeded set of forward / backward passes through
+the host modules and writes every result to an .npz, so that two processes started with different SNWS_* kernel
+switches (they are read once per process) can be compared.   python tests/ab_probe.py <out.npz>"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+import modeling.snorm as sn
+from modeling.blocks import ConvSnRelu
+
+DEV = "cuda:0"
+out = {}
+
+
+def keep(name, t):
+    out[name] = t.detach().float().cpu().numpy()
+
+
+def block_case(tag, cin, cout, n, h, w):
+    torch.manual_seed(7)
+    blk = ConvSnRelu(cin, cout).to(DEV).train()
+    with torch.no_grad():
+        blk[1].mean_weight.copy_(torch.tensor([0.3, -0.2, 0.5]))
+        blk[1].var_weight.copy_(torch.tensor([-0.1, 0.4, 0.2]))
+        blk[1].weight.copy_(torch.rand_like(blk[1].weight) + 0.5)
+        blk[1].bias.copy_(torch.randn_like(blk[1].bias) * 0.1)
+    x = torch.randn(n, cin, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    g = torch.randn(n, cout, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = blk(x)
+    y.backward(g)
+    keep(tag + "_y", y)
+    keep(tag + "_dx", x.grad)
+    for k, p in blk.named_parameters():
+        keep(tag + "_d_" + k, p.grad)
+    keep(tag + "_rm", blk[1].running_mean)
+    keep(tag + "_rv", blk[1].running_var)
+
+
+def sn_case(tag, shape):
+    torch.manual_seed(11)
+    m = sn.SwitchNorm2d(shape[1]).to(DEV).train()
+    with torch.no_grad():
+        m.mean_weight.copy_(torch.tensor([0.1, 0.6, -0.3]))
+        m.var_weight.copy_(torch.tensor([0.2, -0.5, 0.3]))
+        m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+        m.bias.copy_(torch.randn_like(m.bias) * 0.1)
+    x = (torch.randn(*shape, device=DEV) * 2 + 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    g = torch.randn(*shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = m(x)
+    y.backward(g)
+    keep(tag + "_y", y)
+    keep(tag + "_dx", x.grad)
+    for k, p in m.named_parameters():
+        keep(tag + "_d_" + k, p.grad)
+
+
+block_case("b64", 64, 64, 2, 40, 72)          # interior and border tiles of every 3x3 kernel
+block_case("b128", 128, 64, 1, 17, 50)        # ragged sizes, two in-channel tiles
+block_case("b320", 320, 320, 1, 24, 40)       # five channel tiles on both sides
+sn_case("s24", (2, 24, 33, 17))               # stand-alone statistics / backward reduction, odd sizes
+sn_case("s320", (1, 320, 40, 48))             # 240 active threads per workgroup
+torch.cuda.synchronize()
+np.savez(sys.argv[1], **out)

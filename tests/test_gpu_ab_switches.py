@@ -1,0 +1,58 @@
+"""The kernel variants kept behind SNWS_* switches for A/B measurements must compute what the default variants
+compute.  The switches are read once per process, so every variant runs in a process of its own (tests/ab_probe.py)
+and the results are compared here: element-wise kernels and the matrix kernels bit for bit (the variants keep the order
+of every floating-point sum), anything downstream of a re-grouped partial-sum reduction to rounding noise."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp_path, name, env_extra):
+    out = str(tmp_path / (name + ".npz"))
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ab_probe.py"), out], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.fixture(scope="module")
+def default_run(tmp_path_factory):
+    return _run(tmp_path_factory.mktemp("ab"), "default", {})
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(float(np.linalg.norm(b.astype(np.float64))), 1e-30))
+
+
+@pytest.mark.parametrize("switch", ["SNWS_WGRAD9_QW", "SNWS_PRIO", "SNWS_WGRAD_M16"])
+def test_matrix_kernel_variants_are_bit_identical(default_run, tmp_path, switch):
+    # wave split, wave priority and MFMA shape of the 3x3 kernels: same products, same order of every accumulation
+    # (SNWS_WGRAD_M16=0 changes the instruction's internal summation tree: held to rounding noise instead)
+    other = _run(tmp_path, switch, {switch: "0"})
+    for k in default_run.files:
+        a, b = other[k], default_run[k]
+        if switch == "SNWS_WGRAD_M16":
+            assert _rel(a, b) < 2e-3, (switch, k, _rel(a, b))
+        else:
+            assert np.array_equal(a, b), (switch, k, _rel(a, b))
+
+
+def test_streaming_walk_variants_agree(default_run, tmp_path):
+    # contiguous ranges instead of interleaved pieces: the apply passes are element-wise (the forward output of the
+    # fused block - statistics from the conv epilogue - must be identical); stand-alone statistics and backward
+    # reductions group their partial sums differently, so what depends on them may move by rounding noise
+    other = _run(tmp_path, "walk", {"SNWS_SN_INTERLEAVE": "0"})
+    for k in default_run.files:
+        a, b = other[k], default_run[k]
+        if k.startswith("b") and k.endswith("_y"):
+            assert np.array_equal(a, b), k
+        else:
+            assert _rel(a, b) < 3e-3, (k, _rel(a, b))
