@@ -95,6 +95,47 @@ __global__ __launch_bounds__(DT_THREADS) void label_remap_kernel(const S* __rest
   dst[i] = v;
 }
 
+
+// Planar (N, C, H, W) images -> pixel-major (N, H, W, c_pad) in the compute dtype, channels C .. c_pad-1 zero: the layout
+// the convolution kernels read, in one pass (the stock route is a dtype cast, a layout copy, a zero fill and a padded
+// copy).  A workgroup takes 64 consecutive pixels of one image: a wave reads 64 pixels of a channel as one
+// coalesced row, the tile goes through LDS (row stride 65 floats: conflict-free both ways), and thread (pixel p, part q)
+// writes a quarter of the pixel's padded channels, so neighbouring threads write neighbouring bytes.
+constexpr int LAY_PIX = 64, LAY_MAXC = 64, LAY_ITERS = 4;
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const TI* __restrict__ x, TO* __restrict__ y, int C, int64_t HW,
+                                                               int c_pad) {
+  __shared__ float tile[LAY_MAXC][LAY_PIX + 1];
+  const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TI* xn = x + (int64_t)n * C * HW;
+  const int p = tid >> 2, q = tid & 3;               // store phase: 4 threads per pixel, each c_pad / 4 channels
+  const int per = c_pad >> 2;
+  for (int it = 0; it < LAY_ITERS; ++it) {
+    const int64_t p0 = ((int64_t)blockIdx.x * LAY_ITERS + it) * LAY_PIX;
+    if (p0 >= HW) break;                             // block-uniform
+    for (int c = wave; c < c_pad; c += 4) {
+      float v = 0.f;
+      if (c < C && p0 + lane < HW) v = (float)xn[(int64_t)c * HW + p0 + lane];
+      tile[c][lane] = v;
+    }
+    __syncthreads();
+    if (p0 + p < HW) {
+      TO* o = y + ((int64_t)n * HW + p0 + p) * c_pad + q * per;
+      if constexpr (sizeof(TO) == 2) {
+        if (per == 4) {                              // the 14 -> 16 band case: one 8-byte store per thread
+          *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(tile[4 * q][p], tile[4 * q + 1][p]),
+                                                    pack_bf16x2(tile[4 * q + 2][p], tile[4 * q + 3][p]));
+        } else {
+          for (int j = 0; j < per; ++j) o[j] = (TO)tile[q * per + j][p];
+        }
+      } else {
+        for (int j = 0; j < per; ++j) o[j] = (TO)tile[q * per + j][p];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int snws_tile_minmax_blocks(int64_t elems_per_tile) {
@@ -138,5 +179,28 @@ extern "C" int snws_label_remap(const void* src, int src_dtype, float* dst, int6
     default: SNWS_CHECK_ARG(false, "snws_label_remap: unsupported src_dtype %d", src_dtype);
   }
   SNWS_LAUNCH_CHECK("snws_label_remap");
+  return SNWS_OK;
+}
+
+extern "C" int snws_nchw_to_nhwc_pad(const void* x, int in_dtype, void* y, int out_dtype, int N, int C, int H, int W, int c_pad,
+                                     void* stream) {
+  SNWS_CHECK_ARG(x && y, "snws_nchw_to_nhwc_pad: NULL pointer");
+  SNWS_CHECK_ARG(N >= 1 && N <= 65535 && C >= 1 && H >= 1 && W >= 1, "snws_nchw_to_nhwc_pad: bad sizes");
+  SNWS_CHECK_ARG(c_pad >= C && c_pad % 4 == 0 && c_pad <= LAY_MAXC,
+                 "snws_nchw_to_nhwc_pad: c_pad %d must be a multiple of 4 in [C = %d, %d]", c_pad, C, LAY_MAXC);
+  SNWS_CHECK_ARG((in_dtype == SNWS_F32 || in_dtype == SNWS_BF16) && (out_dtype == SNWS_F32 || out_dtype == SNWS_BF16),
+                 "snws_nchw_to_nhwc_pad: dtypes must be F32 or BF16");
+  const int64_t HW = (int64_t)H * W;
+  const dim3 grid((unsigned)cdiv64(HW, LAY_PIX * LAY_ITERS), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == SNWS_F32 && out_dtype == SNWS_F32)
+    nchw_to_nhwc_pad_kernel<float, float><<<grid, 256, 0, st>>>((const float*)x, (float*)y, C, HW, c_pad);
+  else if (in_dtype == SNWS_F32)
+    nchw_to_nhwc_pad_kernel<float, bf16_t><<<grid, 256, 0, st>>>((const float*)x, (bf16_t*)y, C, HW, c_pad);
+  else if (out_dtype == SNWS_F32)
+    nchw_to_nhwc_pad_kernel<bf16_t, float><<<grid, 256, 0, st>>>((const bf16_t*)x, (float*)y, C, HW, c_pad);
+  else
+    nchw_to_nhwc_pad_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, C, HW, c_pad);
+  SNWS_LAUNCH_CHECK("snws_nchw_to_nhwc_pad");
   return SNWS_OK;
 }

@@ -87,7 +87,13 @@ def crop_concat(a, b):
 
 
 def to_device_layout(x, dtype=None):
-    """Input images (N,C,H,W) -> channels-last tensor of the compute dtype."""
+    """Input images (N,C,H,W) -> channels-last tensor of the compute dtype.  A planar batch headed for the bf16 matrix
+    kernels, whose channel count is not a multiple of 16 (the 14 bands), takes ONE pass of the library's layout kernel:
+    cast, transposition and zero-padding to 16 channels at once; the result is the logical (N,C,H,W) slice of that
+    padded buffer and carries the buffer itself for the first convolution (ops.conv_forward)."""
+    if dtype == torch.bfloat16 and x.is_cuda and x.dim() == 4 and not x.requires_grad and x.is_contiguous() and \
+            x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 16 != 0 and x.shape[1] <= 64 and x.shape[0] <= 65535:
+        return ops.planar_to_padded_nhwc(x, dtype)
     if dtype is not None and x.dtype != dtype:
         x = x.to(dtype)
     return x.contiguous(memory_format=torch.channels_last)

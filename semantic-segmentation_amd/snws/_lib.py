@@ -111,6 +111,7 @@ _SIGNATURES = {
     "snws_tile_minmax_blocks": (c_int, [c_int64]),
     "snws_tile_minmax_scale": (c_int, [P, P, c_int, c_int, c_int64, P, P, P]),
     "snws_label_remap": (c_int, [P, c_int, P, c_int64, P]),
+    "snws_nchw_to_nhwc_pad": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_adamw_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
     "snws_comm_unique_id": (c_int, [P]),
     "snws_comm_init": (c_int, [P, c_int, c_int, P]),

@@ -272,6 +272,21 @@ def _pad_channels(x, ld, c_to):
     return out.permute(0, 3, 1, 2), c_to
 
 
+def planar_to_padded_nhwc(x, dtype):
+    """Contiguous NCHW float32 / bfloat16 batch -> logical (N,C,H,W) tensor of `dtype` stored pixel-major with its channels
+    zero-padded to a multiple of 16 (snws_nchw_to_nhwc_pad: one pass); the padded tensor rides along as `_snws_padded`."""
+    require_gpu(x, "input layout")
+    N, C, H, W = x.shape
+    c_pad = (C + 15) // 16 * 16
+    buf = torch.empty((N, H, W, c_pad), dtype=dtype, device=x.device)
+    _launch("input_layout", float(x.element_size() * C + buf.element_size() * c_pad) * N * H * W, "snws_nchw_to_nhwc_pad",
+            _ptr(x), dtype_code(x), _ptr(buf), dtype_code(buf), N, C, H, W, c_pad, _stream())
+    full = buf.permute(0, 3, 1, 2)
+    y = full[:, :C]
+    y._snws_padded = full
+    return y
+
+
 def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
     """y = conv(x, standardized weight) + bias.  Returns (y, stat_part or None, saved) where `saved` is what
     conv_backward needs."""
@@ -289,7 +304,12 @@ def conv_forward(x, prep, bias, want_stats=False, force_direct=False):
     if use_mfma:
         c_run = (C + 15) // 16 * 16
         if c_run != C or ldx % 8 or xs.data_ptr() % 16:
-            xs, ldx = _pad_channels(xs, ldx, c_run)
+            padded = getattr(x, "_snws_padded", None)
+            if padded is not None and padded.shape[1] == c_run and ldx == c_run and padded.dtype == x.dtype and \
+                    padded.data_ptr() == xs.data_ptr() and xs.data_ptr() % 16 == 0:
+                xs = padded       # the input layout kernel already left the padding channels zero
+            else:
+                xs, ldx = _pad_channels(xs, ldx, c_run)
         y = new_nhwc(N, cfg.O, OH, OW, x.dtype, x.device)
         if want_stats:
             T = L.lib().snws_conv_mfma_tiles(H, W)

@@ -1950,3 +1950,25 @@ def test_synchronized_batchnorm_all_ranks_vs_torch(dims, shape):
     ref.eval(); m.eval()
     with torch.no_grad():
         assert relerr(m(xg.detach()), ref(xr.detach())) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 14, 40, 72), (1, 3, 7, 5), (3, 20, 33, 64)])
+def test_input_layout_kernel_matches_torch_route(shape, src):
+    """snws_nchw_to_nhwc_pad (cast + NCHW -> NHWC + zero padding to 16 channels in one pass) against the stock route,
+    bit for bit, and the first block of a model fed through it against the same block fed a channels-last tensor."""
+    from modeling.blocks import ConvSnRelu, to_device_layout
+    torch.manual_seed(3)
+    x = (torch.randn(*shape, device=DEV) * 50).to(src)
+    got = to_device_layout(x, torch.bfloat16)
+    ref = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert got.shape == ref.shape and got.dtype == torch.bfloat16
+    assert torch.equal(got, ref)
+    full = got._snws_padded
+    assert full.shape[1] % 16 == 0 and full.data_ptr() == got.data_ptr()
+    assert float(full[:, shape[1]:].abs().max()) == 0.0
+    blk = ConvSnRelu(shape[1], 64).to(DEV).train()
+    y_fast = blk(got)
+    y_ref = blk(ref)
+    assert torch.equal(y_fast, y_ref)
