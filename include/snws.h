@@ -443,7 +443,7 @@ int snws_label_remap(const void* src, int src_dtype, float* dst, int64_t n, void
 /* snws_nchw_to_nhwc_pad: the planar image batch a data loader delivers (N, C, H, W; train.py:241 `image.cuda()`, consumed by
  *   the first Conv2dws of the model, modeling/UNet3p_SNws.py:98) -> pixel-major (N, H, W, c_pad) in out_dtype with the
  *   channels C .. c_pad-1 zero: the layout the convolution kernels read (14 bands -> 16), one pass.  x: contiguous NCHW of
- *   in_dtype (SNWS_F32 | SNWS_BF16); y: N*H*W*c_pad elements of out_dtype; c_pad: a multiple of 4, C <= c_pad <= 64. */
+ *   in_dtype (SNWS_F32 | SNWS_BF16); y: N*H*W*c_pad elements of out_dtype, 16-byte aligned; c_pad: a multiple of 8 (bf16 out) / 4 (f32 out), C <= c_pad <= 64. */
 int snws_nchw_to_nhwc_pad(const void* x, int in_dtype, void* y, int out_dtype, int N, int C, int H, int W, int c_pad,
                           void* stream);
 

@@ -98,41 +98,58 @@ __global__ __launch_bounds__(DT_THREADS) void label_remap_kernel(const S* __rest
 
 // Planar (N, C, H, W) images -> pixel-major (N, H, W, c_pad) in the compute dtype, channels C .. c_pad-1 zero: the layout
 // the convolution kernels read, in one pass (the stock route is a dtype cast, a layout copy, a zero fill and a padded
-// copy).  A workgroup takes 64 consecutive pixels of one image: a wave reads 64 pixels of a channel as one
-// coalesced row, the tile goes through LDS (row stride 65 floats: conflict-free both ways), and thread (pixel p, part q)
-// writes a quarter of the pixel's padded channels, so neighbouring threads write neighbouring bytes.
-constexpr int LAY_PIX = 64, LAY_MAXC = 64, LAY_ITERS = 4;
-template <typename TI, typename TO>
+// copy).  A workgroup takes 256 consecutive pixels of one image: a wave reads a channel's 256 pixels as one coalesced
+// row (four pixels per lane - one 8- or 16-byte load where the alignment allows, VEC), the tile goes through LDS (row
+// stride 257 floats: conflict-free both ways), and thread p writes pixel p's padded channels, so neighbouring threads
+// write neighbouring bytes.
+constexpr int LAY_PIX = 256, LAY_MAXC = 64;
+template <typename TI, typename TO, bool VEC>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const TI* __restrict__ x, TO* __restrict__ y, int C, int64_t HW,
                                                                int c_pad) {
-  __shared__ float tile[LAY_MAXC][LAY_PIX + 1];
+  extern __shared__ __attribute__((aligned(16))) float lay_tile[];     // [c_pad][LAY_PIX + 1]
   const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t p0 = (int64_t)blockIdx.x * LAY_PIX;
   const TI* xn = x + (int64_t)n * C * HW;
-  const int p = tid >> 2, q = tid & 3;               // store phase: 4 threads per pixel, each c_pad / 4 channels
-  const int per = c_pad >> 2;
-  for (int it = 0; it < LAY_ITERS; ++it) {
-    const int64_t p0 = ((int64_t)blockIdx.x * LAY_ITERS + it) * LAY_PIX;
-    if (p0 >= HW) break;                             // block-uniform
-    for (int c = wave; c < c_pad; c += 4) {
-      float v = 0.f;
-      if (c < C && p0 + lane < HW) v = (float)xn[(int64_t)c * HW + p0 + lane];
-      tile[c][lane] = v;
-    }
-    __syncthreads();
-    if (p0 + p < HW) {
-      TO* o = y + ((int64_t)n * HW + p0 + p) * c_pad + q * per;
-      if constexpr (sizeof(TO) == 2) {
-        if (per == 4) {                              // the 14 -> 16 band case: one 8-byte store per thread
-          *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(tile[4 * q][p], tile[4 * q + 1][p]),
-                                                    pack_bf16x2(tile[4 * q + 2][p], tile[4 * q + 3][p]));
+  for (int c = wave; c < c_pad; c += 4) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+      const TI* src = xn + (int64_t)c * HW + p0 + 4 * lane;
+      if (VEC && p0 + 4 * lane + 3 < HW) {
+        if constexpr (sizeof(TI) == 2) {
+          const uint2 q = *reinterpret_cast<const uint2*>(src);
+          v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+          v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
         } else {
-          for (int j = 0; j < per; ++j) o[j] = (TO)tile[q * per + j][p];
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         }
       } else {
-        for (int j = 0; j < per; ++j) o[j] = (TO)tile[q * per + j][p];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (p0 + 4 * lane + e < HW) v[e] = (float)src[e];
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lay_tile[c * (LAY_PIX + 1) + 4 * lane + e] = v[e];
+  }
+  __syncthreads();
+  if (p0 + tid < HW) {
+    TO* o = y + ((int64_t)n * HW + p0 + tid) * c_pad;
+    const float* t = lay_tile + tid;
+    if constexpr (sizeof(TO) == 2) {
+      for (int c = 0; c + 8 <= c_pad; c += 8) {       // c_pad is a multiple of 8 for 2-byte outputs (host check)
+        uint4 q;
+        q.x = pack_bf16x2(t[(c + 0) * (LAY_PIX + 1)], t[(c + 1) * (LAY_PIX + 1)]);
+        q.y = pack_bf16x2(t[(c + 2) * (LAY_PIX + 1)], t[(c + 3) * (LAY_PIX + 1)]);
+        q.z = pack_bf16x2(t[(c + 4) * (LAY_PIX + 1)], t[(c + 5) * (LAY_PIX + 1)]);
+        q.w = pack_bf16x2(t[(c + 6) * (LAY_PIX + 1)], t[(c + 7) * (LAY_PIX + 1)]);
+        *reinterpret_cast<uint4*>(o + c) = q;
+      }
+    } else {
+      for (int c = 0; c + 4 <= c_pad; c += 4)
+        *reinterpret_cast<float4*>(o + c) = make_float4(t[c * (LAY_PIX + 1)], t[(c + 1) * (LAY_PIX + 1)],
+                                                        t[(c + 2) * (LAY_PIX + 1)], t[(c + 3) * (LAY_PIX + 1)]);
+    }
   }
 }
 
@@ -186,21 +203,28 @@ extern "C" int snws_nchw_to_nhwc_pad(const void* x, int in_dtype, void* y, int o
                                      void* stream) {
   SNWS_CHECK_ARG(x && y, "snws_nchw_to_nhwc_pad: NULL pointer");
   SNWS_CHECK_ARG(N >= 1 && N <= 65535 && C >= 1 && H >= 1 && W >= 1, "snws_nchw_to_nhwc_pad: bad sizes");
-  SNWS_CHECK_ARG(c_pad >= C && c_pad % 4 == 0 && c_pad <= LAY_MAXC,
-                 "snws_nchw_to_nhwc_pad: c_pad %d must be a multiple of 4 in [C = %d, %d]", c_pad, C, LAY_MAXC);
   SNWS_CHECK_ARG((in_dtype == SNWS_F32 || in_dtype == SNWS_BF16) && (out_dtype == SNWS_F32 || out_dtype == SNWS_BF16),
                  "snws_nchw_to_nhwc_pad: dtypes must be F32 or BF16");
+  const int mult = out_dtype == SNWS_BF16 ? 8 : 4;      // whole 16-byte stores per pixel
+  SNWS_CHECK_ARG(c_pad >= C && c_pad % mult == 0 && c_pad <= LAY_MAXC,
+                 "snws_nchw_to_nhwc_pad: c_pad %d must be a multiple of %d in [C = %d, %d]", c_pad, mult, C, LAY_MAXC);
+  SNWS_CHECK_ARG(((uintptr_t)y & 15) == 0, "snws_nchw_to_nhwc_pad: y must be 16-byte aligned");
   const int64_t HW = (int64_t)H * W;
-  const dim3 grid((unsigned)cdiv64(HW, LAY_PIX * LAY_ITERS), N);
+  const dim3 grid((unsigned)cdiv64(HW, LAY_PIX), N);
+  const size_t lds = (size_t)c_pad * (LAY_PIX + 1) * sizeof(float);
+  const int isz = in_dtype == SNWS_F32 ? 4 : 2;
+  const bool vec = HW % 4 == 0 && ((uintptr_t)x % (4 * isz)) == 0;     // every (channel, 4-pixel group) is an aligned vector
   hipStream_t st = (hipStream_t)stream;
-  if (in_dtype == SNWS_F32 && out_dtype == SNWS_F32)
-    nchw_to_nhwc_pad_kernel<float, float><<<grid, 256, 0, st>>>((const float*)x, (float*)y, C, HW, c_pad);
-  else if (in_dtype == SNWS_F32)
-    nchw_to_nhwc_pad_kernel<float, bf16_t><<<grid, 256, 0, st>>>((const float*)x, (bf16_t*)y, C, HW, c_pad);
-  else if (out_dtype == SNWS_F32)
-    nchw_to_nhwc_pad_kernel<bf16_t, float><<<grid, 256, 0, st>>>((const bf16_t*)x, (float*)y, C, HW, c_pad);
-  else
-    nchw_to_nhwc_pad_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, C, HW, c_pad);
+#define LAY(TI, TO)                                                                                                   \
+  do {                                                                                                                \
+    if (vec) nchw_to_nhwc_pad_kernel<TI, TO, true><<<grid, 256, lds, st>>>((const TI*)x, (TO*)y, C, HW, c_pad);        \
+    else nchw_to_nhwc_pad_kernel<TI, TO, false><<<grid, 256, lds, st>>>((const TI*)x, (TO*)y, C, HW, c_pad);           \
+  } while (0)
+  if (in_dtype == SNWS_F32 && out_dtype == SNWS_F32) LAY(float, float);
+  else if (in_dtype == SNWS_F32) LAY(float, bf16_t);
+  else if (out_dtype == SNWS_F32) LAY(bf16_t, float);
+  else LAY(bf16_t, bf16_t);
+#undef LAY
   SNWS_LAUNCH_CHECK("snws_nchw_to_nhwc_pad");
   return SNWS_OK;
 }
