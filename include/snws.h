@@ -237,7 +237,11 @@ int snws_sn_bwd_apply_res(const void* dy, int64_t lddy, const void* x, int64_t l
  * forward-only use (training = 1 still updates the running buffers exactly as snws_sn_mix_b does).
  * Returns SNWS_ERR_INVALID when snws_sn_noalloc_floats(N, HW, C) exceeds the array.  Every call on one GPU shares
  * that GPU's array: calls that overlap in time on one GPU (different streams or threads) race; calls on one stream
- * are ordered and safe. */
+ * are ordered and safe.
+ * snws_sn_noalloc_max_floats() is also the warm-up: the first use on a device looks the array's address up with
+ * hipGetSymbolAddress, which is not a capturable stream operation - call it once per device, with that device
+ * current, BEFORE beginning a stream capture that contains snws_sn_apply_noalloc (without a GPU it only returns the
+ * size). */
 int64_t snws_sn_noalloc_max_floats(void);
 int64_t snws_sn_noalloc_floats(int N, int64_t HW, int C);
 int snws_sn_apply_noalloc(const void* x, int64_t ldx, void* y, int64_t ldy, const void* residual, int64_t ldr, int dtype,
@@ -412,6 +416,13 @@ int snws_ce_blocks(int64_t n_pixels);
 int snws_ce_fwd_bwd(const void* logits, int dtype, int64_t ld, const float* target, int64_t n_pixels, int C,
                     int ignore_index, const float* scale, float* loss_part, void* dlogits, int64_t ldd, int c_write,
                     void* stream);
+/* The same with per-class weights - nn.CrossEntropyLoss(weight=self.weight, ...) at utils/loss.py:148, the weights
+ * train.py:55-67 builds under --use-balanced-weights.  class_weight: C device floats, or NULL (= snws_ce_fwd_bwd).
+ * loss_part sums w[target] * (logsumexp - logit[target]); dlogits = w[target] * (softmax - onehot) * *scale; the
+ * caller's normaliser is the (global) sum of w[target] over valid pixels instead of their count. */
+int snws_ce_fwd_bwd_w(const void* logits, int dtype, int64_t ld, const float* target, int64_t n_pixels, int C,
+                      int ignore_index, const float* scale, const float* class_weight, float* loss_part, void* dlogits,
+                      int64_t ldd, int c_write, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Arg-max of one inference tile written into the full-disk prediction - replaces torch.max(outputs, 1) and
@@ -443,7 +454,8 @@ int snws_label_remap(const void* src, int src_dtype, float* dst, int64_t n, void
 /* snws_nchw_to_nhwc_pad: the planar image batch a data loader delivers (N, C, H, W; train.py:241 `image.cuda()`, consumed by
  *   the first Conv2dws of the model, modeling/UNet3p_SNws.py:98) -> pixel-major (N, H, W, c_pad) in out_dtype with the
  *   channels C .. c_pad-1 zero: the layout the convolution kernels read (14 bands -> 16), one pass.  x: contiguous NCHW of
- *   in_dtype (SNWS_F32 | SNWS_BF16); y: N*H*W*c_pad elements of out_dtype, 16-byte aligned; c_pad: a multiple of 8 (bf16 out) / 4 (f32 out), C <= c_pad <= 64. */
+ *   in_dtype (SNWS_F32 | SNWS_BF16); y: N*H*W*c_pad elements of out_dtype, 16-byte aligned; c_pad: a multiple of 8 (bf16 out) / 4 (f32 out), C <= c_pad <= 48
+ *   (the 256-pixel staging tile then fits the default dynamic-LDS limit). */
 int snws_nchw_to_nhwc_pad(const void* x, int in_dtype, void* y, int out_dtype, int N, int C, int H, int W, int c_pad,
                           void* stream);
 

@@ -294,16 +294,19 @@ def crop_concat(a, b):
 # ----------------------------------------------------------------------------
 # Loss, LR, tiling
 # ----------------------------------------------------------------------------
-def ce_loss_batch_avg(logit, target, ignore_index=255):
-    """utils/loss.py:146-159: mean CE over non-ignored pixels, then divided by the batch size."""
+def ce_loss_batch_avg(logit, target, ignore_index=255, weight=None):
+    """utils/loss.py:146-159: mean CE over non-ignored pixels, then divided by the batch size.  With class weights
+    (utils/loss.py:148, nn.CrossEntropyLoss(weight=w, reduction='mean')) the mean is the weighted one:
+    sum w[t] * ce / sum w[t] over the non-ignored pixels."""
     n, c, h, w = logit.shape
     t = target.long()
     lse = torch.logsumexp(logit, dim=1)
     valid = t != ignore_index
     tc = torch.where(valid, t, torch.zeros_like(t))
     picked = torch.gather(logit, 1, tc[:, None]).squeeze(1)
-    per = (lse - picked) * valid.to(logit.dtype)
-    return per.sum() / valid.sum().to(logit.dtype) / n
+    wt = valid.to(logit.dtype) if weight is None else weight.to(logit.dtype)[tc] * valid.to(logit.dtype)
+    per = (lse - picked) * wt
+    return per.sum() / wt.sum() / n
 
 
 def poly_lr(base_lr, T, N):

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(DT_THREADS) void label_remap_kernel(const S* __rest
 // row (four pixels per lane - one 8- or 16-byte load where the alignment allows, VEC), the tile goes through LDS (row
 // stride 257 floats: conflict-free both ways), and thread p writes pixel p's padded channels, so neighbouring threads
 // write neighbouring bytes.
-constexpr int LAY_PIX = 256, LAY_MAXC = 64;
+// 48 channels x 257 floats = 49 344 B: inside the 64 KB of dynamic LDS a kernel gets without an attribute call
+constexpr int LAY_PIX = 256, LAY_MAXC = 48;
 template <typename TI, typename TO, bool VEC>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const TI* __restrict__ x, TO* __restrict__ y, int C, int64_t HW,
                                                                int c_pad) {

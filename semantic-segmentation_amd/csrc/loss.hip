@@ -13,16 +13,18 @@ constexpr int CE_MAX_C = 64;
 template <typename T>
 __device__ __forceinline__ float ld1(const T* p) { return (float)(*p); }
 
-// loss_part[block] = sum over the block's pixels of (logsumexp - logit[target]) for non-ignored pixels (fixed
-// summation order: bit-reproducible); dlogits = (softmax - onehot) * scale for them, 0 for ignored pixels and for
-// the padding channels C..c_write-1.
+// loss_part[block] = sum over the block's pixels of w[target] * (logsumexp - logit[target]) for non-ignored pixels
+// (fixed summation order: bit-reproducible); dlogits = w[target] * (softmax - onehot) * scale for them, 0 for ignored
+// pixels and for the padding channels C..c_write-1.  w = class_weight (nn.CrossEntropyLoss(weight=...),
+// utils/loss.py:148) or 1 when NULL; a label outside [0, C) that is not ignore_index weighs 0.
 template <typename T, int V>
 __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ logits, int64_t ld, const float* __restrict__ target,
                                                         int64_t npix, int C, int ignore_index, const float* __restrict__ scale_ptr,
+                                                        const float* __restrict__ class_weight,
                                                         float* __restrict__ loss_part, T* __restrict__ dlogits, int64_t ldd,
                                                         int c_write) {
   __shared__ float red[16];
-  const float scale = scale_ptr ? *scale_ptr : 1.f;
+  const float scale0 = scale_ptr ? *scale_ptr : 1.f;
   float acc = 0.f;
   for (int64_t p = (int64_t)blockIdx.x * CE_THREADS + threadIdx.x; p < npix; p += (int64_t)gridDim.x * CE_THREADS) {
     const T* row = logits + p * ld;
@@ -49,6 +51,8 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ lo
     const float tf = target[p];
     const int t = (int)tf;                       // .long(): truncation toward zero
     const bool valid = t != ignore_index;
+    const float wt = class_weight ? ((t >= 0 && t < C) ? class_weight[t] : 0.f) : 1.f;
+    const float scale = scale0 * wt;
     float s = 0.f, gap = 0.f;                    // gap = logit[t] - max, taken BEFORE exponentiating: exp(gap) may underflow
 #pragma unroll
     for (int c = 0; c < CE_MAX_C; ++c)
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ lo
         v[c] = __expf(d);
         s += v[c];
       }
-    if (valid) acc += __logf(s) - gap;            // = logsumexp - logit[t], finite for any finite logits
+    if (valid) acc += wt * (__logf(s) - gap);            // = logsumexp - logit[t], finite for any finite logits
     if (dlogits) {
       const float k = valid ? scale / s : 0.f;
       T* drow = dlogits + p * ldd;
@@ -114,9 +118,9 @@ extern "C" int snws_ce_blocks(int64_t n_pixels) {
   return (int)(b < 2048 ? b : 2048);
 }
 
-extern "C" int snws_ce_fwd_bwd(const void* logits, int dtype, int64_t ld, const float* target, int64_t n_pixels, int C,
-                               int ignore_index, const float* scale, float* loss_part, void* dlogits, int64_t ldd,
-                               int c_write, void* stream) {
+extern "C" int snws_ce_fwd_bwd_w(const void* logits, int dtype, int64_t ld, const float* target, int64_t n_pixels, int C,
+                                 int ignore_index, const float* scale, const float* class_weight, float* loss_part,
+                                 void* dlogits, int64_t ldd, int c_write, void* stream) {
   SNWS_CHECK_ARG(logits && target && loss_part, "snws_ce_fwd_bwd: NULL pointer");
   SNWS_CHECK_ARG(C >= 1 && C <= CE_MAX_C, "snws_ce_fwd_bwd: %d classes outside [1,%d]", C, CE_MAX_C);
   SNWS_CHECK_ARG(n_pixels >= 0 && ld >= C, "snws_ce_fwd_bwd: bad sizes");
@@ -131,16 +135,23 @@ extern "C" int snws_ce_fwd_bwd(const void* logits, int dtype, int64_t ld, const 
   if (dtype == SNWS_BF16) {
     if (vec)
       ce_kernel<bf16_t, 8><<<grid, CE_THREADS, 0, st>>>((const bf16_t*)logits, ld, target, n_pixels, C, ignore_index, scale,
-                                                        loss_part, (bf16_t*)dlogits, ldd, c_write);
+                                                        class_weight, loss_part, (bf16_t*)dlogits, ldd, c_write);
     else
       ce_kernel<bf16_t, 1><<<grid, CE_THREADS, 0, st>>>((const bf16_t*)logits, ld, target, n_pixels, C, ignore_index, scale,
-                                                        loss_part, (bf16_t*)dlogits, ldd, c_write);
+                                                        class_weight, loss_part, (bf16_t*)dlogits, ldd, c_write);
   } else {
     ce_kernel<float, 1><<<grid, CE_THREADS, 0, st>>>((const float*)logits, ld, target, n_pixels, C, ignore_index, scale,
-                                                     loss_part, (float*)dlogits, ldd, c_write);
+                                                     class_weight, loss_part, (float*)dlogits, ldd, c_write);
   }
   SNWS_LAUNCH_CHECK("snws_ce_fwd_bwd");
   return SNWS_OK;
+}
+
+extern "C" int snws_ce_fwd_bwd(const void* logits, int dtype, int64_t ld, const float* target, int64_t n_pixels, int C,
+                               int ignore_index, const float* scale, float* loss_part, void* dlogits, int64_t ldd,
+                               int c_write, void* stream) {
+  return snws_ce_fwd_bwd_w(logits, dtype, ld, target, n_pixels, C, ignore_index, scale, nullptr, loss_part, dlogits, ldd,
+                           c_write, stream);
 }
 
 extern "C" int snws_argmax_stitch(const void* logits, int dtype, int64_t ld, int h, int w, int C, int64_t* pred, int H,

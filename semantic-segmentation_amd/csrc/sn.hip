@@ -1091,7 +1091,14 @@ inline int64_t round64(int64_t v) { return (v + 63) / 64 * 64; }
 
 }  // namespace
 
-extern "C" int64_t snws_sn_noalloc_max_floats(void) { return SN_SCRATCH_FLOATS; }
+// Also the warm-up call: hipGetSymbolAddress is not a capturable stream operation, so a caller that will use
+// snws_sn_apply_noalloc under HIP graph capture calls this once per device (with that device current) beforehand;
+// it resolves and caches the array's address when a device is present and is a plain size query otherwise.
+extern "C" int64_t snws_sn_noalloc_max_floats(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) == hipSuccess && n > 0) (void)scratch_on_current_device();
+  return SN_SCRATCH_FLOATS;
+}
 
 extern "C" int64_t snws_sn_noalloc_floats(int N, int64_t HW, int C) {
   if (N < 1 || HW < 1 || C < 1) return -1;

@@ -92,7 +92,7 @@ def to_device_layout(x, dtype=None):
     cast, transposition and zero-padding to 16 channels at once; the result is the logical (N,C,H,W) slice of that
     padded buffer and carries the buffer itself for the first convolution (ops.conv_forward)."""
     if dtype == torch.bfloat16 and x.is_cuda and x.dim() == 4 and not x.requires_grad and x.is_contiguous() and \
-            x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 16 != 0 and x.shape[1] <= 64 and x.shape[0] <= 65535:
+            x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 16 != 0 and x.shape[1] <= 48 and x.shape[0] <= 65535:
         return ops.planar_to_padded_nhwc(x, dtype)
     if dtype is not None and x.dtype != dtype:
         x = x.to(dtype)

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "snws_comm_destroy": (c_int, [P]),
     "snws_ce_blocks": (c_int, [c_int64]),
     "snws_ce_fwd_bwd": (c_int, [P, c_int, c_int64, P, c_int64, c_int, c_int, P, P, P, c_int64, c_int, P]),
+    "snws_ce_fwd_bwd_w": (c_int, [P, c_int, c_int64, P, c_int64, c_int, c_int, P, P, P, P, c_int64, c_int, P]),
     "snws_argmax_stitch": (c_int, [P, c_int, c_int64, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
 }
 

@@ -54,35 +54,43 @@ def poly_lr(base_lr, it, total_iters):
     return base_lr * pow((1 - 1.0 * it / total_iters), 0.9)
 
 
-def global_ce_loss(logits, target, ignore_index=255, group=None):
-    """The reference loss of the GLOBAL batch, as this rank's additive share: sum of the rank's per-pixel CE over
-    the global count of non-ignored pixels, over the global batch size.  Summed over ranks it equals
-    CrossEntropyLoss(mean)(all logits)/N_global (utils/loss.py:154-157 applied to DataParallel's gathered output,
-    train.py:250-252)."""
-    n = logits.shape[0]
-    t = target.long()
-    ce_sum = F.cross_entropy(logits.float(), t, ignore_index=ignore_index, reduction="sum")
-    cnt = torch.stack([(t != ignore_index).sum().to(torch.float32),
-                       torch.full((), float(n), dtype=torch.float32, device=logits.device)])
-    if _dp(group):
+def _loss_normalisers(target, n, ignore_index, weight, device, group, reduce=True):
+    """[sum over non-ignored pixels of w[target] (their count without class weights), batch size], float32 on the
+    device, summed over the ranks of `group`: the two divisors of utils/loss.py:151-157 for the GLOBAL batch."""
+    t = target.to(torch.int64)
+    valid = t != ignore_index
+    if weight is None:
+        norm = valid.sum().to(torch.float32)
+    else:       # nn.CrossEntropyLoss(weight=w, reduction='mean') divides by the sum of w[target] over valid pixels
+        w = weight.to(device=device, dtype=torch.float32)
+        norm = (w[t.clamp(0, w.numel() - 1)] * valid).sum()
+    # (torch.full is a device fill; torch.tensor(..., device=cuda) would be a blocking host-to-device copy that
+    # stalls the host until the forward pass has drained)
+    cnt = torch.stack([norm, torch.full((), float(n), dtype=torch.float32, device=device)])
+    if reduce and _dp(group):
         from . import ops
         ops.all_reduce(cnt, "sum", group)
+    return cnt
+
+
+def global_ce_loss(logits, target, ignore_index=255, group=None, weight=None):
+    """The reference loss of the GLOBAL batch, as this rank's additive share: sum of the rank's per-pixel (class-
+    weighted) CE over the global normaliser, over the global batch size.  Summed over ranks it equals
+    CrossEntropyLoss(weight, mean)(all logits)/N_global (utils/loss.py:146-157 applied to DataParallel's gathered
+    output, train.py:250-252)."""
+    w = None if weight is None else weight.to(device=logits.device, dtype=torch.float32)
+    ce_sum = F.cross_entropy(logits.float(), target.long(), weight=w, ignore_index=ignore_index, reduction="sum")
+    cnt = _loss_normalisers(target, logits.shape[0], ignore_index, weight, logits.device, group)
     return ce_sum / cnt[0] / cnt[1]
 
 
-def global_ce_loss_fused(raw_logits, n_class, target, ignore_index=255, group=None):
+def global_ce_loss_fused(raw_logits, n_class, target, ignore_index=255, group=None, weight=None):
     """global_ce_loss on the head kernel's raw output (N, Cp, H, W) through the fused forward+backward kernel: the
     soft-max, the loss and d(loss)/d(logits) are produced in one pass over the logits."""
     from . import ops
-    n = raw_logits.shape[0]
-    # (torch.full is a device fill; torch.tensor(..., device=cuda) would be a blocking host-to-device copy that
-    # stalls the host until the forward pass has drained)
-    cnt = torch.stack([(target.to(torch.int64) != ignore_index).sum().to(torch.float32),
-                       torch.full((), float(n), dtype=torch.float32, device=raw_logits.device)])
-    if _dp(group):
-        ops.all_reduce(cnt, "sum", group)
+    cnt = _loss_normalisers(target, raw_logits.shape[0], ignore_index, weight, raw_logits.device, group)
     scale = 1.0 / (cnt[0] * cnt[1])
-    return ops.FusedCEFn.apply(raw_logits, target, n_class, scale, ignore_index)
+    return ops.FusedCEFn.apply(raw_logits, target, n_class, scale, ignore_index, weight)
 
 
 class GradBuckets:
@@ -176,8 +184,11 @@ class Trainer:
     """One-replica training driver with the reference's hyper-parameters as defaults (train.py:384-429)."""
 
     def __init__(self, model, lr=0.002, weight_decay=5e-4, total_iters=1000, ignore_index=255, group=None,
-                 bucket_mb=25.0, fused_loss=None, optimizer="flat"):
+                 bucket_mb=25.0, fused_loss=None, optimizer="flat", class_weight=None):
+        """class_weight: None or a float tensor of per-class loss weights (train.py:55-67, --use-balanced-weights)."""
         self.model = model
+        self.class_weight = class_weight
+        self.val_loss = None
         # classes = output channels of the last registered 1x1 classification conv the forward uses
         head = getattr(model, "cls_head", None) or getattr(model, "output_seg_map")
         self.n_class = head.out_channels
@@ -220,10 +231,10 @@ class Trainer:
                 out = self.model(image)
             finally:
                 self.model.raw_logits = False
-            loss = global_ce_loss_fused(out, self.n_class, target, self.ignore_index, self.group)
+            loss = global_ce_loss_fused(out, self.n_class, target, self.ignore_index, self.group, self.class_weight)
         else:
             out = self.model(image)
-            loss = global_ce_loss(out, target, self.ignore_index, self.group)
+            loss = global_ce_loss(out, target, self.ignore_index, self.group, self.class_weight)
         loss.backward()
         self.buckets.finish()
         self.opt.step()
@@ -234,12 +245,32 @@ class Trainer:
 
     @torch.no_grad()
     def validate(self, batches, evaluator):
-        """train.py:279-304 with the argmax + confusion matrix on the device."""
+        """train.py:279-304 with the argmax + confusion matrix on the device.  Returns the four metrics; the
+        criterion of every validation batch (train.py:291-292, summed over the batches like `val_loss`) is left in
+        self.val_loss, its mean over the batches (the 'Loss:' line, train.py:313) in self.val_loss_mean.  The loss
+        comes from the forward-only form of the fused cross-entropy kernel on the same logits; under data
+        parallelism each batch's sums are global (one all-reduce for the whole validation)."""
+        from . import ops
         self.model.eval()
         evaluator.reset()
+        sums = []
         for image, target in batches:
-            evaluator.add_batch_logits(target, self.model(image))
+            logits = self.model(image)
+            evaluator.add_batch_logits(target, logits)
+            part, _, _ = ops.ce_partials(logits, target, self.n_class, self.ignore_index, self.class_weight)
+            cnt = _loss_normalisers(target, logits.shape[0], self.ignore_index, self.class_weight, logits.device,
+                                    self.group, reduce=False)
+            sums.append(torch.cat([part.sum().reshape(1), cnt]))
         evaluator.sync(group=self.group, all_reduce=True)
+        if sums:
+            s = torch.stack(sums)
+            if _dp(self.group):
+                ops.all_reduce(s, "sum", self.group)
+            per_batch = s[:, 0] / s[:, 1] / s[:, 2]
+            self.val_loss = float(per_batch.sum())
+            self.val_loss_mean = self.val_loss / len(sums)
+        else:
+            self.val_loss, self.val_loss_mean = 0.0, float("nan")
         return (evaluator.Pixel_Accuracy(), evaluator.Pixel_Accuracy_Class(),
                 evaluator.Mean_Intersection_over_Union(), evaluator.Frequency_Weighted_Intersection_over_Union())
 

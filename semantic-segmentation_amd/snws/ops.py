@@ -458,6 +458,8 @@ def share_grad(x):
     """Mark x - about to be consumed by several libsnws ops - for in-place gradient accumulation (see above)."""
     if not (GRAD_SHARE and torch.is_grad_enabled() and x.requires_grad):
         return x
+    if grad_slot(x) is not None:        # already shared: its consumers keep accumulating into the one slot
+        return x
     slot = GradSlot()
     y = _GradJoinFn.apply(x, slot)
     y._snws_gslot = slot
@@ -1723,33 +1725,48 @@ def assemble(buf, parts):
 
 # ------------------------------------------------------------------------------------------------ loss / inference tiles
 class FusedCEFn(torch.autograd.Function):
-    """scale * sum over non-ignored pixels of CrossEntropy(logits, target) (utils/loss.py:146-159 with the division
-    by the valid-pixel count and the batch size folded into `scale`, a device scalar), forward and backward in one
-    pass.  logits: (N, Cp, H, W) channels-last, the first n_class channels are real (Cp > n_class: the padded MFMA
-    head); the gradient of the padding channels is zero."""
+    """scale * sum over non-ignored pixels of w[target] * CrossEntropy(logits, target) (utils/loss.py:146-159 with the
+    division by the normaliser - the valid-pixel count, or the sum of w[target] with class weights - and the batch
+    size folded into `scale`, a device scalar), forward and backward in one pass.  logits: (N, Cp, H, W)
+    channels-last, the first n_class channels are real (Cp > n_class: the padded MFMA head); the gradient of the
+    padding channels is zero.  weight: None or n_class float32 class weights (nn.CrossEntropyLoss(weight=...))."""
 
     @staticmethod
-    def forward(ctx, logits, target, n_class, scale, ignore_index):
-        require_gpu(logits, "cross entropy")
-        N, Cp, H, W = logits.shape
-        xs, ld = as_nhwc(logits)
-        tg = target.detach().to(torch.float32).contiguous()
-        if tuple(tg.shape) != (N, H, W):
-            raise ValueError("cross entropy: target shape %s does not match logits %s" % (tuple(tg.shape), (N, H, W)))
-        npix = N * H * W
-        part = torch.empty(L.lib().snws_ce_blocks(npix), dtype=torch.float32, device=logits.device)
-        dl = new_nhwc(N, Cp, H, W, xs.dtype, logits.device)
-        sc = scale.detach().to(torch.float32).reshape(1).contiguous()
-        _launch("ce_fwd_bwd", float(npix) * (2.0 * xs.element_size() * Cp + 4.0), "snws_ce_fwd_bwd", _ptr(xs),
-                dtype_code(xs), ld, _ptr(tg), npix, int(n_class), int(ignore_index), _ptr(sc), _ptr(part), _ptr(dl), Cp,
-                Cp, _stream())
+    def forward(ctx, logits, target, n_class, scale, ignore_index, weight=None):
+        part, sc, dl = ce_partials(logits, target, n_class, ignore_index, weight, scale, want_grad=True)
         ctx.dl = dl
         return part.sum() * sc[0]
 
     @staticmethod
     def backward(ctx, g):
         dl, ctx.dl = ctx.dl, None
-        return dl.mul_(g.to(dl.dtype)), None, None, None, None
+        return dl.mul_(g.to(dl.dtype)), None, None, None, None, None
+
+
+def ce_partials(logits, target, n_class, ignore_index=255, weight=None, scale=None, want_grad=False):
+    """One launch of the cross-entropy kernel: per-block partial sums of w[target] * CE over the non-ignored pixels
+    (float32, fixed order), the scale as a (1,) device tensor and - with want_grad - d(scale * sum)/d(logits).
+    Without want_grad this is the forward-only form validation uses (train.py:291)."""
+    require_gpu(logits, "cross entropy")
+    N, Cp, H, W = logits.shape
+    xs, ld = as_nhwc(logits)
+    tg = target.detach().to(torch.float32).contiguous()
+    if tuple(tg.shape) != (N, H, W):
+        raise ValueError("cross entropy: target shape %s does not match logits %s" % (tuple(tg.shape), (N, H, W)))
+    wt = None
+    if weight is not None:
+        wt = weight.detach().to(device=logits.device, dtype=torch.float32).contiguous()
+        if wt.numel() != int(n_class):
+            raise ValueError("cross entropy: %d class weights for %d classes" % (wt.numel(), int(n_class)))
+    npix = N * H * W
+    part = torch.empty(L.lib().snws_ce_blocks(npix), dtype=torch.float32, device=logits.device)
+    dl = new_nhwc(N, Cp, H, W, xs.dtype, logits.device) if want_grad else None
+    sc = None if scale is None else scale.detach().to(torch.float32).reshape(1).contiguous()
+    nbytes = float(npix) * ((2.0 if want_grad else 1.0) * xs.element_size() * Cp + 4.0)
+    _launch("ce_fwd_bwd", nbytes, "snws_ce_fwd_bwd_w", _ptr(xs), dtype_code(xs), ld, _ptr(tg), npix, int(n_class),
+            int(ignore_index), _ptr(sc) if sc is not None else None, _ptr(wt) if wt is not None else None, _ptr(part),
+            _ptr(dl) if dl is not None else None, Cp, Cp, _stream())
+    return part, sc, dl
 
 
 def argmax_stitch(logits, n_class, pred, y0, x0, remap_background=False):

@@ -37,9 +37,14 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
     """Class map (H, W) int64 of one (C, H, W) disk that already lives on the device.
 
     model: a network of this package in eval mode semantics (model.eval() is called); disk: float tensor (C, H, W),
-    H = ysize, W = xsize.  normalize: what is applied to each (n, C, block, block) tile batch before the network -
-    "minmax" (default): the per-tile min-max x 255 the training tiles went through
-    (dataloaders/datasets/cloud_dataset.py:127-131) on the HIP kernel of snws.data; a callable; or None.
+    H = ysize, W = xsize.  normalize: what is applied before the network -
+    "minmax" (default): to each (n, C, block, block) tile batch, the per-tile min-max x 255 the TRAINING tiles went
+    through (dataloaders/datasets/cloud_dataset.py:127-131), on the HIP kernel of snws.data - the network then sees
+    what it was trained on; "minmax_disk": one min-max x 255 over the whole disk before tiling, which is what the
+    reference's own inference dataset does with its image file (utils/preddataset.py:42-56); a callable applied to
+    each tile batch; or None (the disk is already scaled).  A constant tile (max == min: an all-space corner block)
+    scales to 0/0 = NaN exactly as the numpy lines do; NaNs are set to 0 afterwards as utils/preddataset.py:71 does,
+    so such a tile gets the class of an all-zero input instead of an arg-max over NaN logits.
     Under torch.distributed the tile list is dealt round-robin to the ranks; every rank returns the full map: the
     ranks' partial maps are merged with one all-reduce(max) of (tile index, class) keys, which reproduces "later
     tile wins".  No halo exchange is needed: every tile is a self-contained forward."""
@@ -62,6 +67,10 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
     model.eval()
     if raw:
         model.raw_logits = True
+    cd = torch.bfloat16 if getattr(model, "compute_dtype", None) == torch.bfloat16 else torch.float32
+    if normalize == "minmax_disk":
+        from . import data
+        disk = torch.nan_to_num_(data.normalize_tiles(disk, cd), nan=0.0)
     mine = [(i, o) for i, o in enumerate(offs) if i % world == rank]
     pred = torch.zeros((H, W), dtype=torch.int64, device=disk.device)
     tile_pred = torch.empty((block, block), dtype=torch.int64, device=disk.device) if merge else None
@@ -71,8 +80,9 @@ def predict_disk(model, disk, block=512, overlap=0, n_class=None, tiles_per_forw
             batch = torch.stack([disk[:, y:y + block, x:x + block] for _, (x, y) in chunk])
             if normalize == "minmax":
                 from . import data
-                cd = getattr(model, "compute_dtype", None)
-                batch = data.normalize_tiles(batch, torch.bfloat16 if cd == torch.bfloat16 else torch.float32)
+                batch = torch.nan_to_num_(data.normalize_tiles(batch, cd), nan=0.0)
+            elif normalize == "minmax_disk":
+                pass
             elif normalize is not None:
                 batch = normalize(batch)
             logits = model(batch)

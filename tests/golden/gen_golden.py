@@ -376,6 +376,19 @@ def gen_misc():
     save("g78_misc", **out)
 
 
+def gen_weighted_ce():
+    """g8w: the reference's criterion built with class weights (train.py:55-67 -> SegmentationLosses(weight=...),
+    utils/loss.py:146-159): weighted mean over the non-ignored pixels, / batch size; loss and d(loss)/d(logits)."""
+    w = t32(fill((10,), 73, 0.8, 1.3))
+    crit = SegmentationLosses(weight=w, cuda=False).build_loss(mode="ce")
+    logit = t32(fill((3, 10, 9, 7), 71, 2.0)).requires_grad_(True)
+    tgt = t32(label_pattern((3, 9, 7), 10, ignore_every=5))
+    loss = crit(logit, tgt)
+    loss.backward()
+    save("g8w_weighted_ce", weight=w.numpy(), logit=logit.detach().numpy(), target=tgt.numpy(),
+         loss=np.array(loss.item(), np.float64), dlogit=logit.grad.numpy())
+
+
 # --------------------------------------------------------------------------- G9
 def _ste_round(t, dtype=torch.bfloat16):
     """Value rounded to `dtype`, gradient passed straight through."""
@@ -499,6 +512,155 @@ def gen_bf16_storage(warm_steps=20, n_filters=16):
     save("g9_bf16_storage", **arrays)
 
 
+# --------------------------------------------------------------------------- G9b / G5c
+class _Bf16StorageAll:
+    """_Bf16Storage for models that hold more than ConvSnRelu blocks (UNet3p_res_ocr_SNws.py:211-377): every tensor
+    the MI355X path stores in bf16 is rounded straight-through in the REFERENCE, from outside: every filter that
+    enters F.conv2d (the standardized one for Conv2dws), the output of every nn.Conv2d (Conv2dws included), of every
+    nn.ReLU (block outputs, the residual blocks' two uses of their ReLU, the BatchNorm + ReLU pairs of the OCR head),
+    of every nn.Upsample, both soft-max results (F.softmax), the object-region features (output of
+    SpatialGather_Module) and the attention context (input of f_up)."""
+
+    def __init__(self, model):
+        self.model, self.handles, self.orig = model, [], None
+
+    def __enter__(self):
+        import torch.nn as nn
+        import torch.nn.functional as F
+        rnd_out = lambda mod, inp, out: _ste_round(out)                      # noqa: E731
+        for name, m in self.model.named_modules():
+            if isinstance(m, (nn.Conv2d, nn.ReLU, nn.Upsample)) or type(m).__name__ == "SpatialGather_Module":
+                self.handles.append(m.register_forward_hook(rnd_out))
+            if name.endswith("object_context_block.f_up"):
+                self.handles.append(m.register_forward_pre_hook(lambda mod, inp: (_ste_round(inp[0]),)))
+        self.orig = (F.conv2d, F.softmax)
+        o_conv, o_soft = self.orig
+        F.conv2d = lambda input, weight, *a, **kw: o_conv(input, _ste_round(weight), *a, **kw)
+        F.softmax = lambda *a, **kw: _ste_round(o_soft(*a, **kw))
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.conv2d, F.softmax = self.orig
+        for h in self.handles:
+            h.remove()
+
+
+def gen_bf16_storage_ocr(warm_steps=20, n_filters=16):
+    """g9b: gen_bf16_storage's protocol for the reference UNet3p_res_ocr_SNws(14, 16, 10) (Dropout2d p = 0): a trained
+    state (20 float32 AdamW steps of the reference), parameters rounded to bf16 values, then on one more batch the
+    float32 step, the step with bf16 storage roundings (_Bf16StorageAll) and that step with every parameter moved by a
+    relative 1e-6 (the reference's own self-noise in that mode)."""
+    crit = SegmentationLosses(weight=None, cuda=False).build_loss(mode="ce")
+    model = UNet3p_res_ocr_SNws(14, n_filters, 10, 1, 1)
+    det_init_ocr(model)
+    model.ocr_distri_head.conv_bn_dropout[3].p = 0.0
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=5e-4)
+    batches = [synth_batch_learnable(4, 14, 64, 200 + j) for j in range(4)]
+    for i in range(warm_steps):
+        img, lab = batches[i % 4]
+        opt.zero_grad()
+        loss = crit(model(img), lab)
+        loss.backward()
+        opt.step()
+        print("warm-up step", i, "loss", loss.item(), flush=True)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    img, lab = synth_batch_learnable(4, 14, 64, 211)
+    img = img.to(torch.bfloat16).float()
+
+    def run(storage, perturb=0.0):
+        model.load_state_dict(state0)
+        if perturb:
+            with torch.no_grad():
+                for k, p in enumerate(model.parameters()):
+                    p.mul_(1.0 + perturb * t32(fill(tuple(p.shape), 300 + k, 1.0)))
+        model.zero_grad()
+        model.train()
+        with (_Bf16StorageAll(model) if storage else contextlib.nullcontext()):
+            out = model(img)
+            loss = crit(out, lab)
+            loss.backward()
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+                 for n, p in model.named_parameters()}
+        bufs = {n: b.detach().clone() for n, b in model.named_buffers()}
+        return out.detach().clone(), float(loss.item()), grads, bufs
+
+    def l2(a, b):
+        return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+
+    def cat(g):
+        return torch.cat([v.flatten() for v in g.values()])
+
+    lo32, loss32, g32, _ = run(False)
+    lob, lossb, gb, bufb = run(True)
+    lop, lossp, gp, _ = run(True, perturb=1e-6)
+    arrays = {"warm_steps": np.array(warm_steps), "n_filters": np.array(n_filters),
+              "logits_f32": lo32.numpy(), "loss_f32": np.array(loss32), "logits_bf16": lob.numpy(),
+              "loss_bf16": np.array(lossb),
+              "noise_logits": np.array(l2(lop, lob)), "noise_grads_all": np.array(l2(cat(gp), cat(gb))),
+              "storage_logits": np.array(l2(lob, lo32)), "storage_grads_all": np.array(l2(cat(gb), cat(g32)))}
+    names = []
+    for n, p in model.named_parameters():
+        names.append(n)
+        arrays["param:" + n] = state0[n].to(torch.bfloat16).view(torch.int16).numpy()
+        arrays["grad16:" + n], arrays["gscale:" + n] = _pack_scaled_f16(gb[n])
+        arrays["noise:" + n] = np.array(l2(gp[n], gb[n]))
+        arrays["storage:" + n] = np.array(l2(gb[n], g32[n]))
+    for n, b in model.named_buffers():
+        arrays["buf0:" + n] = state0[n].numpy()
+        arrays["buf1:" + n] = bufb[n].numpy()
+    arrays["param_names"] = np.array(names)
+    print("res-OCR self noise: logits %.4f grads(all) %.4f | storage vs f32: logits %.4f grads(all) %.4f" %
+          (arrays["noise_logits"], arrays["noise_grads_all"], arrays["storage_logits"], arrays["storage_grads_all"]))
+    save("g9b_bf16_storage_res_ocr", **arrays)
+
+
+def gen_loss_curve_bf16_storage(n_filters=16, runs=3):
+    """g5c: gen_loss_curve's 200 steps of the reference UNet3p_SNws(14, 16, 10) with bf16 storage roundings
+    (_Bf16Storage; master parameters and optimizer stay float32, as on the MI355X bf16 tier).  Run `runs` times, run r
+    with the initial parameters moved by a relative r x 1e-6: how far apart the reference's own curves end up in that
+    mode is the yardstick for any other implementation of it (stored as losses_perturbed)."""
+    steps = 200
+    crit = SegmentationLosses(weight=None, cuda=False).build_loss(mode="ce")
+    batches = [synth_batch_learnable(4, 14, 64, 200 + j) for j in range(4)]
+    curves = []
+    for r in range(runs):
+        model = UNet3p_SNws(14, n_filters, 10, 1, 1)
+        det_init(model)
+        if r:
+            with torch.no_grad():
+                for k, p in enumerate(model.parameters()):
+                    p.mul_(1.0 + r * 1e-6 * t32(fill(tuple(p.shape), 300 + k, 1.0)))
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=5e-4)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sched = LR_Scheduler("poly", 2e-3, 1, steps)
+        losses = []
+        for i in range(steps):
+            img, lab = batches[i % 4]
+            with contextlib.redirect_stdout(io.StringIO()):
+                sched(opt, i, 0, 0.0)
+            opt.zero_grad()
+            with _Bf16Storage(model, 10):
+                loss = crit(model(img.to(torch.bfloat16).float()), lab)
+                loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            if i % 20 == 0:
+                print("run", r, "step", i, "loss", losses[-1], flush=True)
+        curves.append(losses)
+    c = np.array(curves, np.float64)
+    print("bf16-storage reference curves: max relative spread between runs %.4g, of the 10-step moving average %.4g"
+          % (float((np.abs(c[1:] - c[0]) / c[0]).max()),
+             float(max((np.abs(np.convolve(x, np.ones(10) / 10, "valid") - np.convolve(c[0], np.ones(10) / 10, "valid"))
+                        / np.convolve(c[0], np.ones(10) / 10, "valid")).max() for x in c[1:]))))
+    save("g5c_loss_curve_nf16_bf16_storage", losses=c[0], losses_perturbed=c[1:])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g78"]
     if "g1" in which:
@@ -519,5 +681,11 @@ if __name__ == "__main__":
         gen_evaluator()
     if "g78" in which:
         gen_misc()
+    if "g8w" in which:      # class-weighted criterion
+        gen_weighted_ce()
     if "g9" in which:       # bf16-storage run of the reference (not part of the default list: takes a few minutes)
         gen_bf16_storage()
+    if "g9b" in which:      # the same protocol for UNet3p_res_ocr_SNws
+        gen_bf16_storage_ocr()
+    if "g5c" in which:      # the reference's 200-step curve WITH bf16 storage, three times (self-noise of the curve)
+        gen_loss_curve_bf16_storage()

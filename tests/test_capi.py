@@ -157,3 +157,14 @@ def test_saver_layout_and_checkpoint_format(tmp_path):
     assert (epoch, bp) == (1, 0.5) and torch.equal(net2[0].weight, net[0].weight)
     with pytest.raises(RuntimeError):
         checkpoint.load_checkpoint(str(tmp_path / "missing.pth.tar"), net2)
+
+
+def test_share_grad_is_idempotent():
+    """Marking an already shared tensor again must not stack a second identity node whose slot no consumer fills."""
+    import torch
+    from snws import ops
+    x = torch.ones(1, 2, 3, 3, requires_grad=True) * 2.0
+    y = ops.share_grad(x)
+    if ops.GRAD_SHARE:
+        assert ops.grad_slot(y) is not None
+    assert ops.share_grad(y) is y

@@ -577,3 +577,152 @@ def test_res_ocr_full_size_one_pass_forms_match_the_composed_ones():
     print("one-pass vs composed OCR head: loss %.5f / %.5f, gradient errors median %.4f p90 %.4f max %.4f"
           % (res[True][0], res[False][0], errs[len(errs) // 2], errs[int(len(errs) * 0.9)], errs[-1]))
     assert errs[len(errs) // 2] < 2e-2 and errs[int(len(errs) * 0.9)] < 6e-2, (errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
+
+
+def _l2(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def _gpu_step(model, img, lab, dtype):
+    model = model.to(DEV).train()
+    model.compute_dtype = dtype
+    model.zero_grad(set_to_none=True)
+    logits = model(img.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits.float(), lab.to(DEV).long(), ignore_index=255) / img.shape[0]
+    loss.backward()
+    grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
+    return logits.detach().cpu(), float(loss.detach()), grads
+
+
+def test_unet3p_snws_benchmark_width_f32_vs_oracle():
+    """The benchmark's model at the benchmark's width and tile size - UNet3p_SNws(14, 64, 10, 1, 1)
+    (modeling/UNet3p_SNws.py:42-160) on one 512 x 512 tile, stock initialisation, forward + CE/N + backward - element
+    by element against the CPU oracle: 1024-channel tap sources, the up-sampled convolution with k = 16 at 512 x 512,
+    the 320 -> 320 fusion convolution over many tiles per workgroup slot and the full-size classification head all
+    meet the oracle here, not only checksums.  float32 tier: logits, loss and running buffers within 1e-3 of the
+    float32 oracle; gradients per class of parameter against the float64 oracle, held to 1e-3 + 3x the float32 oracle's
+    own distance from it (random-label gradients are cancellation-dominated in float32 on either side)."""
+    import statistics
+    import time
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from oracle import snws_oracle as O
+    torch.manual_seed(21)
+    model = UNet3p_SNws(14, 64, 10, 1, 1)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(1, 14, 512, 512, generator=g) * 255.0
+    lab = torch.randint(0, 10, (1, 512, 512), generator=g).float()
+    lab[0, :5] = 255.0
+    t0 = time.time()
+    ostate = {k: v.clone() for k, v in state.items()}
+    logits_ref, loss_ref, grads_ref = O.model_step("unet3p", ostate, img, lab)
+    t1 = time.time()
+    _, _, g64 = O.model_step("unet3p", {k: v.double() for k, v in state.items()}, img.double(), lab)
+    t2 = time.time()
+    logits, loss, grads = _gpu_step(model, img, lab, torch.float32)
+    print("UNet3p_SNws(64) 1x512^2 f32: oracle f32 %.1f s, f64 %.1f s; logits L2 rel %.3g, loss %.6f (oracle %.6f)"
+          % (t1 - t0, t2 - t1, _l2(logits, logits_ref), loss, loss_ref))
+    assert tuple(logits.shape) == (1, 10, 512, 512)
+    assert _l2(logits, logits_ref) < 1e-3
+    assert float((logits - logits_ref).abs().max()) < 1e-3 * float(logits_ref.abs().max())
+    assert abs(loss - loss_ref) < 1e-3 * abs(loss_ref)
+    mine, theirs = {}, {}
+    for name in grads:
+        assert bool(torch.isfinite(grads[name]).all()), name
+        cls = name.rsplit(".", 1)[1]
+        mine.setdefault(cls, []).append(_l2(grads[name], g64[name]))
+        theirs.setdefault(cls, []).append(_l2(grads_ref[name], g64[name]))
+    worst_ref = max(max(v) for v in theirs.values())
+    for cls in mine:
+        print("  gradients .%s vs float64 oracle: GPU median %.3g max %.3g; float32 oracle median %.3g max %.3g"
+              % (cls, statistics.median(mine[cls]), max(mine[cls]), statistics.median(theirs[cls]), max(theirs[cls])))
+        assert statistics.median(mine[cls]) < 1e-3 + 3.0 * statistics.median(theirs[cls]), cls
+        assert max(mine[cls]) < 1e-3 + 3.0 * worst_ref, cls
+    for name, b in model.named_buffers():
+        assert _l2(b, ostate[name]) < 1e-3, name
+
+
+def test_unet3p_snws_benchmark_width_bf16_vs_oracle():
+    """The same model, width and tile size on the bf16 MFMA path (the benchmark's configuration), against the CPU
+    oracle run with the SAME storage format (filters, conv outputs, block outputs and up-sampled maps rounded to bf16,
+    arithmetic float32; that mode reproduces the reference run with bf16 storage hooks, fixture g9).
+    (1) Stock initialisation, random labels: bf16 storage alone moves this 34-block network's logits by several per
+    cent oracle-to-oracle (printed), so the MFMA path is held to 0.6x that storage noise against the same-storage
+    oracle and its loss to 2e-2.
+    (2) A trained state - 40 bf16 AdamW steps of THIS library on a learnable synthetic target at the same size, the
+    parameters then rounded to bf16 values and handed to both sides - is the well-conditioned regime the stated bars
+    are meant for: logits and loss within 2e-2 (L2) of the same-storage oracle; the whole gradient vector within 2e-2 +
+    the oracle's own self-noise in that mode (its distance from itself after a relative 1e-6 change of every
+    parameter, measured here by a second oracle run)."""
+    import os
+    import sys
+    import time
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from oracle import snws_oracle as O
+    from snws import harness
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import patterns
+    torch.manual_seed(22)
+    model = UNet3p_SNws(14, 64, 10, 1, 1)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    img = (torch.rand(1, 14, 512, 512, generator=g) * 255.0).bfloat16().float()
+    lab = torch.randint(0, 10, (1, 512, 512), generator=g).float()
+    lab[0, :5] = 255.0
+    t0 = time.time()
+    logits_ref, loss_ref, _ = O.model_step("unet3p", {k: v.clone() for k, v in state.items()}, img, lab)
+    logits_r16, loss_r16, _ = O.model_step("unet3p", {k: v.clone() for k, v in state.items()}, img, lab,
+                                           act_round=torch.bfloat16)
+    t1 = time.time()
+    logits, loss, grads = _gpu_step(model, img, lab, torch.bfloat16)
+    noise = _l2(logits_r16, logits_ref)
+    print("UNet3p_SNws(64) 1x512^2 bf16, stock init: two oracle runs %.1f s; bf16 storage alone (oracle vs oracle) %.3g; "
+          "GPU vs bf16-storage oracle %.3g, vs float32 oracle %.3g; loss %.5f (oracles %.5f / %.5f)"
+          % (t1 - t0, noise, _l2(logits, logits_r16), _l2(logits, logits_ref), loss, loss_r16, loss_ref))
+    assert _l2(logits, logits_r16) < 0.6 * noise
+    assert _l2(logits, logits_ref) < 1.5 * noise + 1e-2
+    assert abs(loss - loss_r16) < 2e-2 * abs(loss_r16)
+    assert all(bool(torch.isfinite(v).all()) for v in grads.values())
+
+    # ---- (2) trained state
+    model = model.to(DEV)
+    model.compute_dtype = torch.bfloat16
+    tr = harness.Trainer(model, lr=2e-3, weight_decay=5e-4, total_iters=200)
+    batches = [patterns.synth_batch_learnable(1, 14, 512, 400 + j) for j in range(4)]
+    batches = [(i.bfloat16().float().to(DEV), l.to(DEV)) for i, l in batches]
+    first = last = None
+    for it in range(40):
+        last = float(tr.step(*batches[it % 4]))
+        first = last if first is None else first
+    tr.close()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    img, lab = patterns.synth_batch_learnable(1, 14, 512, 411)
+    img = img.bfloat16().float()
+    t0 = time.time()
+    ostate = {k: v.clone() for k, v in state.items()}
+    logits_r16, loss_r16, grads_r16 = O.model_step("unet3p", ostate, img, lab, act_round=torch.bfloat16)
+    pert = {}
+    for k, (name, v) in enumerate(state.items()):
+        pert[name] = v.clone() if O.is_buffer(name) else \
+            v * (1.0 + 1e-6 * patterns.t32(patterns.fill(tuple(v.shape), 300 + k, 1.0)))
+    logits_p, _, grads_p = O.model_step("unet3p", pert, img, lab, act_round=torch.bfloat16)
+    t1 = time.time()
+    names = list(grads_r16)
+    cat = lambda d: torch.cat([d[n].detach().flatten().double().cpu() for n in names])     # noqa: E731
+    noise_l, noise_g = _l2(logits_p, logits_r16), _l2(cat(grads_p), cat(grads_r16))
+    logits, loss, grads = _gpu_step(model, img, lab, torch.bfloat16)
+    e_l, e_g = _l2(logits, logits_r16), _l2(cat(grads), cat(grads_r16))
+    print("UNet3p_SNws(64) 1x512^2 bf16, after 40 training steps (loss %.4f -> %.4f): two oracle runs %.1f s; logits vs "
+          "bf16-storage oracle %.4g (oracle self-noise %.4g); loss %.6f vs %.6f; gradients (all, L2) %.4g (self-noise %.4g)"
+          % (first, last, t1 - t0, e_l, noise_l, loss, loss_r16, e_g, noise_g))
+    assert last < 0.7 * first
+    assert e_l < 2e-2
+    assert abs(loss - loss_r16) < 2e-2 * abs(loss_r16)
+    assert e_g < 2e-2 + noise_g
+    for name, b in model.named_buffers():
+        ref_b = ostate[name]
+        assert float((b.detach().cpu() - ref_b).abs().max()) <= 2e-2 * float(ref_b.abs().max()) + 1e-4, name

@@ -1116,6 +1116,75 @@ def test_fused_cross_entropy_vs_torch(dtype, cp):
     assert abs(float(loss) - float(ref2)) <= 1e-5 * abs(float(ref2))
 
 
+@pytest.mark.parametrize("dtype,cp", [(torch.float32, 10), (torch.bfloat16, 16)])
+def test_fused_cross_entropy_class_weights_golden(dtype, cp):
+    """Class-weighted criterion (nn.CrossEntropyLoss(weight=w) / N, utils/loss.py:146-159 with train.py:55-67's
+    weights) against the REFERENCE's loss and gradient (fixture g8w), through both loss routes of the harness:
+    the fused kernel on (padded) raw logits and the torch route; plus the kernel's forward-only form."""
+    from snws import harness, ops
+    g = load("g8w_weighted_ce")
+    w = torch.from_numpy(g["weight"]).to(DEV)
+    target = torch.from_numpy(g["target"]).to(DEV)
+    base = torch.from_numpy(g["logit"]).to(dtype)
+    N, C, H, W = base.shape
+    raw = torch.zeros(N, cp, H, W, dtype=dtype)
+    raw[:, :C] = base
+    raw = raw.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    loss = harness.global_ce_loss_fused(raw, C, target, 255, None, w)
+    loss.backward()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert abs(float(loss) - float(g["loss"])) <= tol * abs(float(g["loss"]))
+    assert relerr(raw.grad[:, :C].float(), g["dlogit"]) < tol
+    if cp > C:
+        assert float(raw.grad[:, C:].abs().max()) == 0.0
+    plain = base.to(DEV).float().requires_grad_(True)
+    loss2 = harness.global_ce_loss(plain, target, 255, None, w)
+    loss2.backward()
+    assert abs(float(loss2) - float(g["loss"])) <= tol * abs(float(g["loss"]))
+    assert relerr(plain.grad, g["dlogit"]) < tol
+    part, _, dl = ops.ce_partials(raw.detach(), target, C, 255, w)
+    assert dl is None
+    valid = target.long() != 255
+    norm = float((w[target.long().clamp(0, C - 1)] * valid).sum())
+    assert abs(float(part.sum()) / norm / N - float(g["loss"])) <= tol * abs(float(g["loss"]))
+
+
+def test_trainer_validation_loss_and_class_weights():
+    """Trainer.validate leaves the criterion summed over the validation batches (train.py:291-292) in val_loss; with
+    class weights the training step's loss and gradients equal the torch route's."""
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    from snws import harness
+    from utils.metrics import Evaluator
+    w = torch.linspace(0.5, 2.0, 10)
+    batches = [patterns.synth_batch(2, 14, 64, 101 + j) for j in range(3)]
+    batches = [(i.to(DEV), l.to(DEV)) for i, l in batches]
+    batches[1][1][0, :7] = 255.0
+    grads, losses = [], []
+    for fused in (False, True):
+        model = UNet3p_SNws(14, 4, 10, 1, 1)
+        patterns.det_init(model)
+        model = model.to(DEV)
+        tr = harness.Trainer(model, fused_loss=fused, class_weight=w)
+        tr.opt.step = lambda *a, **k: None
+        losses.append(float(tr.step(*batches[1])))
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters()})
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[0])
+    for n in grads[0]:
+        assert relerr(grads[1][n], grads[0][n]) < 1e-4 or float(grads[0][n].abs().max()) < 1e-7, n
+    for cw in (None, w):
+        tr.class_weight = cw
+        ev = Evaluator(10)
+        tr.validate(batches, ev)
+        model.eval()
+        want = 0.0
+        with torch.no_grad():
+            for img, lab in batches:
+                want += float(torch.nn.functional.cross_entropy(
+                    model(img).float(), lab.long(), weight=None if cw is None else cw.to(DEV), ignore_index=255)) / img.shape[0]
+        assert abs(tr.val_loss - want) <= 1e-5 * abs(want)
+        assert abs(tr.val_loss_mean - want / 3) <= 1e-5 * abs(want)
+
+
 def test_trainer_fused_loss_matches_unfused():
     """One Trainer.step with the fused loss head gives the same loss and the same parameter gradients as the
     float32-logits + torch cross-entropy path."""
@@ -1191,6 +1260,17 @@ def test_predict_disk_matches_tile_by_tile():
             for (x, y) in offs:
                 ref2[y:y + block, x:x + block] = torch.argmax(model(disk[None, :, y:y + block, x:x + block])[0], dim=0)
         assert torch.equal(raw, ref2)
+    # whole-disk scaling before tiling (utils/preddataset.py:42-56) == scaling the disk with the oracle, then raw tiles
+    whole = torch.from_numpy(O.normalize_tile(disk.cpu().numpy())).to(DEV)
+    assert torch.equal(tiles.predict_disk(model, disk, block=64, overlap=0, tiles_per_forward=3, normalize="minmax_disk"),
+                       tiles.predict_disk(model, whole, block=64, overlap=0, tiles_per_forward=3, normalize=None))
+    # a constant tile (0/0 under per-tile scaling) is classified like an all-zero tile, not by an arg-max over NaN
+    flat = disk.clone()
+    flat[:, :64, :64] = 3.0
+    got = tiles.predict_disk(model, flat, block=64, overlap=0, tiles_per_forward=3)
+    with torch.no_grad():
+        want = torch.argmax(model(torch.zeros(1, 14, 64, 64, device=DEV))[0], dim=0)
+    assert torch.equal(got[:64, :64], want)
 
 
 def test_tile_minmax_scale_and_label_remap_bit_exact():
@@ -1954,7 +2034,7 @@ def test_synchronized_batchnorm_all_ranks_vs_torch(dims, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("src", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 14, 40, 72), (1, 3, 7, 5), (3, 20, 33, 64)])
+@pytest.mark.parametrize("shape", [(2, 14, 40, 72), (1, 3, 7, 5), (3, 20, 33, 64), (1, 44, 9, 11), (1, 50, 9, 11)])
 def test_input_layout_kernel_matches_torch_route(shape, src):
     """snws_nchw_to_nhwc_pad (cast + NCHW -> NHWC + zero padding to 16 channels in one pass) against the stock route,
     bit for bit, and the first block of a model fed through it against the same block fed a channels-last tensor."""
@@ -1965,6 +2045,9 @@ def test_input_layout_kernel_matches_torch_route(shape, src):
     ref = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert got.shape == ref.shape and got.dtype == torch.bfloat16
     assert torch.equal(got, ref)
+    if shape[1] > 48:       # beyond the one-pass kernel's 48 padded channels: the stock cast + layout copy
+        assert not hasattr(got, "_snws_padded")
+        return
     full = got._snws_padded
     assert full.shape[1] % 16 == 0 and full.data_ptr() == got.data_ptr()
     assert float(full[:, shape[1]:].abs().max()) == 0.0

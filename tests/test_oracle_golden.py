@@ -295,6 +295,16 @@ def test_tiles_lr_ce_golden():
     close(logit.grad, g["ce_dlogit"], rtol=1e-5, atol=1e-7)
 
 
+def test_weighted_ce_golden():
+    """Class-weighted criterion (utils/loss.py:148 with the weights of train.py:55-67) against the reference's output."""
+    g = load("g8w_weighted_ce")
+    logit = torch.from_numpy(g["logit"]).requires_grad_(True)
+    loss = O.ce_loss_batch_avg(logit, torch.from_numpy(g["target"]), weight=torch.from_numpy(g["weight"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    close(logit.grad, g["dlogit"], rtol=1e-5, atol=1e-7)
+
+
 def test_loss_curve_golden_prefix():
     """First 12 steps of the 200-step AdamW/poly curve (the full curve is the GPU test's target)."""
     g = load("g5_loss_curve")

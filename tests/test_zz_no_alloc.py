@@ -51,10 +51,12 @@ def _case(L, seed, N, H, W, C, dtype, relu, with_res, training):
     got = torch.empty_like(x)
     torch.cuda.synchronize()
     before = torch.cuda.memory_allocated()
+    free_before = torch.cuda.mem_get_info()[0]      # the driver's view: sees a hipMalloc inside the library too
     L.call("snws_sn_apply_noalloc", _ptr(x), C, _ptr(got), C, _ptr(res), C if with_res else 0, dt, _ptr(gamma), _ptr(beta),
            _ptr(mw), _ptr(vw), _ptr(rm_b), _ptr(rv_b), N, H * W, C, 1e-5, 0.997, int(training), 1, 1, int(relu), None)
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] >= free_before
     assert torch.equal(got, want), (N, H, W, C, dtype)
     assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
     if training:
@@ -66,7 +68,7 @@ def _case(L, seed, N, H, W, C, dtype, relu, with_res, training):
 def test_noalloc_switchnorm_matches_standalone_entry_points():
     from snws import _lib as L
     lib = L.lib()
-    assert lib.snws_sn_noalloc_max_floats() == 4 << 20
+    assert lib.snws_sn_noalloc_max_floats() == 4 << 20       # also resolves the array's address on this device
     # two calls in a row on one GPU, the second with a smaller input: the shared array still holds the first call's
     # partial sums and coefficients, none of which may leak into the second result
     _case(L, 1, 4, 96, 80, 64, torch.bfloat16, True, False, True)
