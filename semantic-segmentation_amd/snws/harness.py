@@ -214,9 +214,12 @@ class Trainer:
         ops.weights_changed()
 
     def close(self):
-        """Give the model back: its Conv2dws modules standardize on every call again, like the reference."""
+        """Give the model back: its Conv2dws modules standardize on every call again, like the reference, and the
+        flat optimizer lets go of the parameters' gradient slots (the Trainer must not step again afterwards)."""
         from . import ops
         ops.set_filter_cache(self.model, False)
+        if hasattr(self.opt, "release"):
+            self.opt.release()
 
     def step(self, image, target):
         """train.py:246-255.  Returns this rank's share of the global loss (a 0-d tensor; no host sync)."""

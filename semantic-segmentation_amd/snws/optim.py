@@ -39,6 +39,7 @@ class FlatAdamW:
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
         self._touched = [False] * len(self.params)
+        self._hooks = []
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 n = p.numel()
@@ -46,7 +47,7 @@ class FlatAdamW:
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 p.grad = None
                 ops.GRAD_SINKS[p.data_ptr()] = (self.flat_g, o, n, [False], weakref.ref(self))
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
                                   amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
                                   fused=None)]
@@ -57,12 +58,26 @@ class FlatAdamW:
 
         def hook(p):
             self._touched[i] = True
-            if p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:     # not produced in place: move it into the slot
+            if p.grad is None:      # every share of this gradient was added inside the slot by the producing kernels
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+            elif p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:     # not produced in place: move it into the slot
                 with torch.no_grad():
                     slot = self.flat_g[o:o + p.numel()].view(p.shape)
                     slot.copy_(p.grad)
                     p.grad = slot
         return hook
+
+    def release(self):
+        """Detach from the parameters: their gradient slots and hooks are removed, so a later backward outside this
+        optimizer produces ordinary .grad tensors (the parameters keep living in the flat parameter buffer)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            sink = ops.GRAD_SINKS.get(p.data_ptr())
+            if sink is not None and sink[4]() is self:
+                del ops.GRAD_SINKS[p.data_ptr()]
+            p.grad = None
 
     # -------------------------------------------------------------------------------------------- torch.optim surface
     def zero_grad(self, set_to_none=True):

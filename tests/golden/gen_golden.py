@@ -518,7 +518,7 @@ class _Bf16StorageAll:
     the MI355X path stores in bf16 is rounded straight-through in the REFERENCE, from outside: every filter that
     enters F.conv2d (the standardized one for Conv2dws), the output of every nn.Conv2d (Conv2dws included), of every
     nn.ReLU (block outputs, the residual blocks' two uses of their ReLU, the BatchNorm + ReLU pairs of the OCR head),
-    of every nn.Upsample, both soft-max results (F.softmax), the object-region features (output of
+    of every nn.Upsample, both attention soft-max results (F.softmax on 3-D inputs), the object-region features (output of
     SpatialGather_Module) and the attention context (input of f_up)."""
 
     def __init__(self, model):
@@ -536,7 +536,9 @@ class _Bf16StorageAll:
         self.orig = (F.conv2d, F.softmax)
         o_conv, o_soft = self.orig
         F.conv2d = lambda input, weight, *a, **kw: o_conv(input, _ste_round(weight), *a, **kw)
-        F.softmax = lambda *a, **kw: _ste_round(o_soft(*a, **kw))
+        # (nn.Softmax(0) over SwitchNorm's three mixing weights, snorm.py:68-70, also lands in F.softmax: those stay
+        # float32 on the MI355X path - only the two attention soft-maxes over (B, K, HW) / (B, HW, K) are stored)
+        F.softmax = lambda x, *a, **kw: _ste_round(o_soft(x, *a, **kw)) if x.dim() >= 3 else o_soft(x, *a, **kw)
         return self
 
     def __exit__(self, *exc):
@@ -546,11 +548,17 @@ class _Bf16StorageAll:
             h.remove()
 
 
-def gen_bf16_storage_ocr(warm_steps=20, n_filters=16):
+def gen_bf16_storage_ocr(warm_steps=20, n_filters=16, write=True):
     """g9b: gen_bf16_storage's protocol for the reference UNet3p_res_ocr_SNws(14, 16, 10) (Dropout2d p = 0): a trained
-    state (20 float32 AdamW steps of the reference), parameters rounded to bf16 values, then on one more batch the
-    float32 step, the step with bf16 storage roundings (_Bf16StorageAll) and that step with every parameter moved by a
-    relative 1e-6 (the reference's own self-noise in that mode)."""
+    state (20 float32 AdamW steps of the reference), parameters rounded to bf16 values, then on one more batch
+      * the plain float32 step,
+      * the step with bf16 storage roundings (_Bf16StorageAll) and FLOAT64 arithmetic between the roundings - the
+        expected values: what the bf16-storage network computes when nothing but the storage format rounds,
+      * the same with the reference's float32 arithmetic ("f32gap_*": its distance from the float64-arithmetic run;
+        on this data SwitchNorm's var_ln = mean(var_in + mean_in^2) - mean_ln^2 (snorm.py:48-50,54-55) cancels in
+        float32, which moves first-layer outputs by 1e-3 and flips a tenth of the bf16 roundings that follow),
+      * the float64-arithmetic step with every parameter moved by a relative 1e-6 ("noise_*": the bf16-storage
+        network's sensitivity to rounding flips alone)."""
     crit = SegmentationLosses(weight=None, cuda=False).build_loss(mode="ce")
     model = UNet3p_res_ocr_SNws(14, n_filters, 10, 1, 1)
     det_init_ocr(model)
@@ -572,16 +580,17 @@ def gen_bf16_storage_ocr(warm_steps=20, n_filters=16):
     img, lab = synth_batch_learnable(4, 14, 64, 211)
     img = img.to(torch.bfloat16).float()
 
-    def run(storage, perturb=0.0):
+    def run(storage, dtype, perturb=0.0):
+        model.to(dtype)
         model.load_state_dict(state0)
         if perturb:
             with torch.no_grad():
                 for k, p in enumerate(model.parameters()):
-                    p.mul_(1.0 + perturb * t32(fill(tuple(p.shape), 300 + k, 1.0)))
+                    p.mul_(1.0 + perturb * t32(fill(tuple(p.shape), 300 + k, 1.0)).to(dtype))
         model.zero_grad()
         model.train()
         with (_Bf16StorageAll(model) if storage else contextlib.nullcontext()):
-            out = model(img)
+            out = model(img.to(dtype))
             loss = crit(out, lab)
             loss.backward()
         grads = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
@@ -593,15 +602,18 @@ def gen_bf16_storage_ocr(warm_steps=20, n_filters=16):
         return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
 
     def cat(g):
-        return torch.cat([v.flatten() for v in g.values()])
+        return torch.cat([v.flatten().double() for v in g.values()])
 
-    lo32, loss32, g32, _ = run(False)
-    lob, lossb, gb, bufb = run(True)
-    lop, lossp, gp, _ = run(True, perturb=1e-6)
+    lo32, loss32, g32, _ = run(False, torch.float32)
+    lob, lossb, gb, bufb = run(True, torch.float64)
+    lof, lossf, gf, _ = run(True, torch.float32)
+    lop, lossp, gp, _ = run(True, torch.float64, perturb=1e-6)
     arrays = {"warm_steps": np.array(warm_steps), "n_filters": np.array(n_filters),
-              "logits_f32": lo32.numpy(), "loss_f32": np.array(loss32), "logits_bf16": lob.numpy(),
+              "logits_f32": lo32.numpy(), "loss_f32": np.array(loss32), "logits_bf16": lob.float().numpy(),
               "loss_bf16": np.array(lossb),
               "noise_logits": np.array(l2(lop, lob)), "noise_grads_all": np.array(l2(cat(gp), cat(gb))),
+              "f32gap_logits": np.array(l2(lof, lob)), "f32gap_grads_all": np.array(l2(cat(gf), cat(gb))),
+              "f32gap_loss": np.array(abs(lossf - lossb) / abs(lossb)),
               "storage_logits": np.array(l2(lob, lo32)), "storage_grads_all": np.array(l2(cat(gb), cat(g32)))}
     names = []
     for n, p in model.named_parameters():
@@ -609,14 +621,20 @@ def gen_bf16_storage_ocr(warm_steps=20, n_filters=16):
         arrays["param:" + n] = state0[n].to(torch.bfloat16).view(torch.int16).numpy()
         arrays["grad16:" + n], arrays["gscale:" + n] = _pack_scaled_f16(gb[n])
         arrays["noise:" + n] = np.array(l2(gp[n], gb[n]))
+        arrays["f32gap:" + n] = np.array(l2(gf[n], gb[n]))
         arrays["storage:" + n] = np.array(l2(gb[n], g32[n]))
     for n, b in model.named_buffers():
         arrays["buf0:" + n] = state0[n].numpy()
-        arrays["buf1:" + n] = bufb[n].numpy()
+        arrays["buf1:" + n] = bufb[n].float().numpy() if bufb[n].is_floating_point() else bufb[n].numpy()
     arrays["param_names"] = np.array(names)
-    print("res-OCR self noise: logits %.4f grads(all) %.4f | storage vs f32: logits %.4f grads(all) %.4f" %
-          (arrays["noise_logits"], arrays["noise_grads_all"], arrays["storage_logits"], arrays["storage_grads_all"]))
-    save("g9b_bf16_storage_res_ocr", **arrays)
+    print("res-OCR bf16 storage: rounding-flip noise logits %.4f grads(all) %.4f | float32 arithmetic vs float64: logits %.4f "
+          "grads(all) %.4f | storage vs f32: logits %.4f grads(all) %.4f" %
+          (arrays["noise_logits"], arrays["noise_grads_all"], arrays["f32gap_logits"], arrays["f32gap_grads_all"],
+           arrays["storage_logits"], arrays["storage_grads_all"]))
+    model.float()
+    if write:
+        save("g9b_bf16_storage_res_ocr", **arrays)
+    return arrays
 
 
 def gen_loss_curve_bf16_storage(n_filters=16, runs=3):

@@ -911,6 +911,59 @@ def test_res_ocr_bf16_vs_oracle():
     assert l2(logits.detach(), logits_ref) < 1.5 * l2(logits_r16, logits_ref)
 
 
+def test_res_ocr_bf16_vs_reference_run_with_bf16_storage():
+    """Whole-model bf16 bar for UNet3p_res_ocr_SNws against REFERENCE output: fixture g9b holds the reference model
+    (14, 16, 10; Dropout2d p = 0) in a trained state, run with bf16 storage roundings applied from outside and float64
+    arithmetic between them (the expected values), plus two yardsticks: how far that result moves after a relative
+    1e-6 change of the parameters ("noise": logits 0.7 %, whole gradient vector 26 %) and how far the reference's own
+    float32 arithmetic lands from it ("f32gap": 0.55 % / 16 %).  Gated for the MFMA path: logits and loss within the
+    stated 2e-2 of the bf16-storage reference.  Whole-network gradients of this model are not reproducible under bf16
+    storage by any two implementations (the reference's float32 and float64 runs differ by 16 %), so the gradient vector
+    is held to 2e-2 + 1.5x the larger yardstick and the per-tensor median likewise; the backward kernels themselves are
+    held to 2e-2 per op and per block elsewhere in this file."""
+    import statistics
+    from modeling.UNet3p_res_ocr_SNws import UNet3p_res_ocr_SNws
+    g = load("g9b_bf16_storage_res_ocr")
+    state, img, lab, ref_grads = patterns.load_bf16_storage_fixture(g)
+    model = UNet3p_res_ocr_SNws(14, int(g["n_filters"]), 10, 1, 1)
+    model.ocr_distri_head.conv_bn_dropout[3].p = 0.0
+    sd = model.state_dict()
+    model.load_state_dict({k: state[k].reshape(sd[k].shape) for k in sd})
+    model = model.to(DEV).train()
+    model.compute_dtype = torch.bfloat16
+    logits = model(img.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, lab.to(DEV).long(), ignore_index=255) / img.shape[0]
+    loss.backward()
+
+    def l2(a, b):
+        a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+        return float((a - b).norm() / max(float(b.norm()), 1e-30))
+    params = dict(model.named_parameters())
+    names = [str(n) for n in g["param_names"] if params[str(n)].grad is not None]
+    got = torch.cat([params[n].grad.flatten().double().cpu() for n in names])
+    ref = torch.cat([ref_grads[n].flatten() for n in names])
+    e_b, e_f, e_g = l2(logits, g["logits_bf16"]), l2(logits, g["logits_f32"]), l2(got, ref)
+    yard_g = max(float(g["noise_grads_all"]), float(g["f32gap_grads_all"]))
+    per = [l2(params[n].grad.reshape(-1), ref_grads[n].reshape(-1)) for n in names]
+    per_yard = [max(float(g["noise:" + n]), float(g["f32gap:" + n])) for n in names]
+    print("res-OCR bf16 vs reference with bf16 storage: logits %.4g (its rounding-flip noise %.4g, its own float32 gap %.4g; "
+          "storage alone %.4g), vs float32 reference %.4g; loss %.6f vs %.6f; gradients (all, L2) %.4g (noise %.4g, "
+          "float32 gap %.4g); per tensor: median %.4g (yardstick median %.4g)"
+          % (e_b, float(g["noise_logits"]), float(g["f32gap_logits"]), float(g["storage_logits"]), e_f, float(loss),
+             float(g["loss_bf16"]), e_g, float(g["noise_grads_all"]), float(g["f32gap_grads_all"]),
+             statistics.median(per), statistics.median(per_yard)))
+    assert e_b < 2e-2
+    assert abs(float(loss) - float(g["loss_bf16"])) < 2e-2 * float(g["loss_bf16"])
+    assert e_g < 2e-2 + 1.5 * yard_g
+    assert statistics.median(per) < 2e-2 + 1.5 * statistics.median(per_yard)
+    for n in names:
+        assert torch.isfinite(params[n].grad).all(), n
+    for k, b in model.named_buffers():
+        if b.is_floating_point():
+            ref_b = torch.from_numpy(g["buf1:" + k]).reshape(b.shape)
+            assert float((b.detach().cpu() - ref_b).abs().max()) <= 2e-2 * float(ref_b.abs().max()) + 1e-4, k
+
+
 def test_unet3p_bf16_vs_oracle():
     """Mid-size UNet3p_SNws (n_filters 16, 64x64, batch 2) in bf16 on the MFMA path.
 
@@ -1060,11 +1113,14 @@ def test_loss_curve_f32_tracks_reference():
 
 
 def test_loss_curve_bf16_tracks_reference():
-    """The same 200 steps at n_filters=16 (MFMA-aligned widths) in bf16 track the reference's float32 curve.
-    Training amplifies rounding differences (the f32 run above already drifts from 1e-7 to 1e-2 in 200 steps; two
-    summation orders of the same bf16 kernels give curves up to 25 % apart at single steps), so: the first 5 steps,
-    before the amplification, within 5 %; every step within 35 %; the 10-step moving average within 30 %; the
-    final level (mean of the last 10 steps) within 15 %; and the loss must come down by more than half."""
+    """The same 200 steps at n_filters=16 (MFMA-aligned widths) in bf16 track (a) the reference's 200-step curve run
+    WITH bf16 storage roundings (fixture g5c: the reference model under the g9 hooks, float32 master weights and
+    optimizer) and (b) its float32 curve (g5b).  Training amplifies rounding differences: g5c holds the reference's own
+    bf16-storage curve three times, from initial parameters a relative 1e-6 apart, and those runs end up to 19 % apart
+    at single steps and 17 % in the 10-step moving average - two correct implementations cannot agree better.  Gates
+    against (a): the first 5 steps, before the amplification, within 2e-2; every step within 0.10 + the reference's own
+    spread; the moving average within 0.05 + its own spread; the final level (last 10 steps) within 0.05 + its own spread (11 %).  Against (b), the float32
+    curve, the looser bounds a storage format justifies (5 % / 35 % / 30 % / 15 %)."""
     from modeling.UNet3p_SNws import UNet3p_SNws
     path = os.path.join(G, "g5b_loss_curve_nf16.npz")
     if not os.path.exists(path):
@@ -1084,6 +1140,21 @@ def test_loss_curve_bf16_tracks_reference():
     assert sm.max() < 0.30
     assert abs(got[-10:].mean() - ref[-10:].mean()) < 0.15 * ref[-10:].mean()
     assert got[-1] < 0.5 * got[0]
+    gc = load("g5c_loss_curve_nf16_bf16_storage")
+    refc, others = gc["losses"], gc["losses_perturbed"]
+    mov = lambda v: np.convolve(v, ker, "valid")        # noqa: E731
+    spread = float(max((np.abs(o - refc) / refc).max() for o in others))
+    spread_sm = float(max((np.abs(mov(o) - mov(refc)) / mov(refc)).max() for o in others))
+    relc = np.abs(got - refc) / refc
+    smc = np.abs(mov(got) - mov(refc)) / mov(refc)
+    print("bf16 curve vs the reference's bf16-storage curve: first 5 steps %.4g, max rel dev %.4g (reference's own spread "
+          "%.4g), moving-average dev %.4g (own spread %.4g), final %.5f vs %.5f"
+          % (relc[:5].max(), relc.max(), spread, smc.max(), spread_sm, got[-10:].mean(), refc[-10:].mean()))
+    assert relc[:5].max() < 2e-2
+    assert relc.max() < 0.10 + spread
+    assert smc.max() < 0.05 + spread_sm
+    spread_end = float(max(abs(o[-10:].mean() - refc[-10:].mean()) for o in others)) / refc[-10:].mean()
+    assert abs(got[-10:].mean() - refc[-10:].mean()) < (0.05 + spread_end) * refc[-10:].mean()
 
 
 # ---------------------------------------------------------------- fused loss, tiled inference

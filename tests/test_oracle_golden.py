@@ -363,6 +363,46 @@ def test_bf16_storage_mode_matches_reference_run_with_bf16_storage():
             close(sb[k].double(), g["buf1:" + k].astype(np.float64), rtol=2e-2, atol=1e-4)
 
 
+def test_bf16_storage_mode_res_ocr_matches_reference_run_with_bf16_storage():
+    """The same pinning for UNet3p_res_ocr_SNws (fixture g9b, gen_golden.py::gen_bf16_storage_ocr: the reference model
+    in a trained state, run with bf16 storage roundings applied from outside on every filter, convolution output,
+    ReLU output, up-sampled map, both soft-max results, the region features and the attention context).  The
+    expected values are the reference with FLOAT64 arithmetic between the roundings; the fixture also records how far
+    that result moves after a relative 1e-6 change of every parameter ("noise_*": logits 0.7 %, the gradient vector
+    26 %; per tensor 2 % at a few SwitchNorm mixing vectors, 10-80 % in the encoder) and how far the reference's own
+    float32 arithmetic lands from it ("f32gap_*": 0.55 % / 16 %).  With bf16 storage this model's whole-network
+    gradients are not reproducible by ANY two implementations, the reference's float32 and float64 runs included, so
+    the oracle is gated on the logits / loss (1.5x self-noise, and the 2e-2 bar) and on the gradients only as far as
+    the recorded self-noise allows (the whole vector, and the median over the tensors)."""
+    g = load("g9b_bf16_storage_res_ocr")
+    state, img, lab, ref_grads = patterns.load_bf16_storage_fixture(g)
+    st = O.make_state("unet3p_res_ocr", 14, int(g["n_filters"]), 10)
+    assert set(st.keys()) == set(state.keys())
+    st = {k: state[k].reshape(st[k].shape).clone() for k in st}
+
+    def l2(a, b):
+        a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+        return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+    lo32, loss32, _ = O.model_step("unet3p_res_ocr", {k: v.clone() for k, v in st.items()}, img, lab)
+    assert l2(lo32, g["logits_f32"]) < 1e-3 and abs(loss32 - float(g["loss_f32"])) < 1e-3 * float(g["loss_f32"])
+    sb = {k: v.clone() for k, v in st.items()}
+    lob, lossb, gb = O.model_step("unet3p_res_ocr", sb, img, lab, act_round=torch.bfloat16)
+    noise_l, noise_g = float(g["noise_logits"]), float(g["noise_grads_all"])
+    e_l = l2(lob, g["logits_bf16"])
+    names = [str(n) for n in g["param_names"]]
+    e_g = l2(torch.cat([gb[n].flatten().double() for n in names]), torch.cat([ref_grads[n].flatten() for n in names]))
+    print("res-OCR bf16-storage oracle vs reference run: logits %.4g (self-noise %.4g), loss %.6f vs %.6f, gradients %.4g "
+          "(self-noise %.4g)" % (e_l, noise_l, lossb, float(g["loss_bf16"]), e_g, noise_g))
+    assert e_l < 1.5 * noise_l and e_l < 2e-2
+    assert abs(lossb - float(g["loss_bf16"])) < 2e-2 * float(g["loss_bf16"])
+    assert e_g < 2.0 * noise_g
+    import statistics
+    per = [l2(gb[n].reshape(-1), ref_grads[n].reshape(-1)) for n in names if float(ref_grads[n].abs().max()) > 0]
+    per_noise = [max(float(g["noise:" + n]), float(g["f32gap:" + n])) for n in names if float(ref_grads[n].abs().max()) > 0]
+    assert statistics.median(per) < 2e-2 + 1.5 * statistics.median(per_noise)
+
+
 def test_unet_odd_input_golden():
     """UNet_SNws on a 75 x 75 input: ceil-mode pooling + x2 up-sampling leave decoder maps larger than the skips and
     the reference's CropConcat zero-pads the skips (UNet_SNws.py:35-39); output 80 x 80."""
