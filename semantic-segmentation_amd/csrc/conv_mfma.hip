@@ -53,7 +53,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 // Diagnostics build (-DSNWS_TIMING): shader-clock cycles the forward kernel's workgroups spend waiting for staged data,
 // in the matrix phase and in the epilogue ([0..3]), and the 3x3 wgrad's per pixel tile waiting / multiplying ([4..7]),
 // summed over workgroups (wave 0 only); snws_dbg_read copies and clears them.
-__device__ unsigned long long snws_dbg[8];
+__device__ unsigned long long snws_dbg[16];   // [8..15]: the ping-pong 3x3 wgrad (see conv_wgrad9p_kernel)
 #define SNWS_T(var) const long long var = clock64()
 #else
 #define SNWS_T(var)
@@ -1610,6 +1610,343 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9q_kernel(WgradArgs a) {
   wgrad9_body<true, BIAS, true, true, PRIO>(a, smem, (int)xcd_remap(blockIdx.x, gridDim.x));
 }
 
+// ------------------------------------------------------------------------------------------------- 3x3 wgrad, ping-pong
+// conv_wgrad9q_kernel relies on two independent workgroups per CU to cover each other's staging; left to themselves
+// the two drift into lock-step (multiply together at half speed each, then stage together with the matrix pipe idle).
+// Here ONE 8-wave workgroup per CU holds both roles and alternates them by construction: waves 0-3 (group A) and
+// waves 4-7 (group B) each own an (out tile, in tile) pair - one wave of each group per SIMD - and every phase ends in
+// a workgroup barrier: while one group multiplies its pixel tile, the other issues the LDS-DMA copies for its next
+// one and waits for them.  The matrix pipe never sees two waves at once and never waits for a copy that fits into
+// one matrix phase.  When the two pairs share the in-channel tile and the pixel range (neighbouring out tiles of one
+// launch: the common case) they also share the x halo tile: it is staged ONCE per pixel tile, half by each group,
+// into one of two x buffers (the next tile's copy lands while this tile is still being read), so a phase stages 54 KB
+// instead of 76 KB.  Otherwise each group stages its own x tile into "its" buffer.  Partial tiles and their layout are
+// those of conv_wgrad9q_kernel (same reduction kernel, bit-identical results: the per-wave accumulation order over
+// pixel tiles is the same).  No bias gradient: inside a Conv2dws -> SwitchNorm block it comes in closed form from the
+// SwitchNorm backward, and a launch that does want it takes conv_wgrad9q_kernel.
+struct W9pItem {
+  int cot, cit, split, pair, t_begin, n;   // n = pixel tiles of this item (0: no such item)
+};
+
+__device__ __forceinline__ W9pItem w9p_item(const WgradArgs& a, int item, int nitems, int npairs, int ntiles) {
+  W9pItem it;
+  it.pair = item % npairs;
+  it.split = item / npairs;
+  it.cot = it.pair % a.coTiles;
+  it.cit = it.pair / a.coTiles;
+  it.t_begin = it.split * a.tilesPerSplit;
+  int t_end = it.t_begin + a.tilesPerSplit;
+  if (t_end > ntiles) t_end = ntiles;
+  it.n = item < nitems ? t_end - it.t_begin : 0;
+  return it;
+}
+
+// rounds [J0, J1) of the x halo tile of pixel tile t (piece lw + 4j: 8 halo pixels x 64 channels = 1 KB).  The tile
+// base is wave-uniform; a lane's offset inside the halo walks from piece to piece by a two-way recurrence (32 halo
+// pixels further in the 34-wide halo rows), so a piece costs a handful of vector instructions and the copies go out
+// back to back - the group that stages has one matrix phase of its partner to get them issued AND landed.
+template <int J0, int J1>
+__device__ __forceinline__ void w9p_stage_x(const WgradArgs& a, unsigned char* x_lds, int lw, int lane, int t, int cit) {
+  using G = WgGeom<64, 9>;
+  // per-lane constants are recomputed from an opaque copy of the lane id on every call: hoisted out of the tile loop
+  // they would sit in registers across the accumulator-heavy matrix phase and spill - and a spill reload in HERE
+  // waits for vmcnt(0), i.e. for every copy issued so far to land
+  asm volatile("" : "+v"(lane));
+  int tt = t;
+  const int tx = tt % a.tilesX; tt /= a.tilesX;
+  const int ty = tt % a.tilesY;
+  const int n = tt / a.tilesY;
+  const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+  const int q = lane >> 3;
+  const int chunk = (lane & 7) ^ (((q >> 1) & 1) << 2);
+  const bool ch_ok = cit * 64 + chunk * 8 < a.Cin;
+  const bool interior = y0 >= 1 && y0 + WG_TH < a.H && x0 >= 1 && x0 + WG_TW < a.W;
+  // (for a border tile the base may point in front of the image: it is only dereferenced for pixels inside)
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x + (((int64_t)n * a.H + y0 - 1) * a.W + x0 - 1) * a.ldx + cit * 64);
+  const int rowb = a.W * (int)a.ldx * 2, pixb = (int)a.ldx * 2;
+  const int pix0 = 8 * lw + q + 32 * J0;
+  int py = pix0 / G::HWd, px = pix0 - py * G::HWd;
+  int xo = py * rowb + px * pixb + chunk * 16;
+  if (interior) {
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+      const int i = lw + 4 * j;
+      if (i < G::XNI) {
+        const bool ok = ch_ok && (j < G::JX - 1 || py < G::HHt);
+        const void* s_ = ok ? (const void*)(xb + xo) : (const void*)snws_zero_page;
+        glds16(s_, x_lds + i * 1024);
+        const bool wrap = px >= 2;
+        xo += wrap ? rowb - 2 * pixb : 32 * pixb;
+        px += wrap ? -2 : 32;
+        py += wrap ? 1 : 0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+      const int i = lw + 4 * j;
+      if (i < G::XNI) {
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool ok = ch_ok && py < G::HHt && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const void* s_ = ok ? (const void*)(xb + xo) : (const void*)snws_zero_page;
+        glds16(s_, x_lds + i * 1024);
+        const bool wrap = px >= 2;
+        xo += wrap ? rowb - 2 * pixb : 32 * pixb;
+        px += wrap ? -2 : 32;
+        py += wrap ? 1 : 0;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void w9p_stage_dy(const WgradArgs& a, unsigned char* dy_lds, int lw, int lane, int t, int cot) {
+  using G = WgGeom<64, 9>;
+  asm volatile("" : "+v"(lane));
+  int tt = t;
+  const int tx = tt % a.tilesX; tt /= a.tilesX;
+  const int ty = tt % a.tilesY;
+  const int n = tt / a.tilesY;
+  const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+  const int q = lane >> 3;
+  const int chunk = (lane & 7) ^ (((q >> 1) & 1) << 2);
+  const int gx = x0 + 8 * lw + q;
+  const bool col_ok = cot * 64 + chunk * 8 < a.Cout && gx < a.W;
+  const unsigned char* dyb = reinterpret_cast<const unsigned char*>(a.dy + (((int64_t)n * a.H + y0) * a.W + x0) * a.lddy + cot * 64);
+  const int rowb = a.W * (int)a.lddy * 2;
+  int off = (8 * lw + q) * (int)a.lddy * 2 + chunk * 16;
+#pragma unroll
+  for (int j = 0; j < G::JD; ++j) {      // piece lw + 4j = tile row j, columns 8*lw .. 8*lw + 7
+    const bool ok = col_ok && y0 + j < a.H;
+    const void* s_ = ok ? (const void*)(dyb + off) : (const void*)snws_zero_page;
+    glds16(s_, dy_lds + (lw + 4 * j) * 1024);
+    off += rowb;
+  }
+}
+
+#ifndef W9P_PRIO
+#define W9P_PRIO 2
+#endif
+#ifndef W9P_NOSTAGE
+#define W9P_NOSTAGE 0      // 1 (diagnostics only, wrong results): no copies after the first tile - the matrix phases alone
+#endif
+__global__ __launch_bounds__(512) void conv_wgrad9p_kernel(WgradArgs a) {
+  using G = WgGeom<64, 9>;
+  constexpr int XB = ((G::X_BYTES + 15) / 16) * 16;
+  constexpr int JX = G::JX, JXH = (G::JX + 1) / 2;        // x rounds: all / the first group's share of a shared tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const xbuf = smem;                        // two x halo buffers
+  unsigned char* const dybuf = smem + 2 * XB;              // one dy tile per group
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, lw = wave & 3;
+  const int npairs = a.coTiles * a.ciTiles;
+  const int ntiles = a.N * a.tilesY * a.tilesX;
+  const int nitems = npairs * ((ntiles + a.tilesPerSplit - 1) / a.tilesPerSplit);
+  const int wg = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const W9pItem itA = w9p_item(a, 2 * wg, nitems, npairs, ntiles), itB = w9p_item(a, 2 * wg + 1, nitems, npairs, ntiles);
+  const W9pItem me = grp ? itB : itA;
+  const bool shared = itB.n > 0 && itA.split == itB.split && itA.cit == itB.cit;      // then itA.n == itB.n
+  const int nloop = itA.n > itB.n ? itA.n : itB.n;
+  unsigned char* const dy_lds = dybuf + grp * G::DY_BYTES;
+
+  // v_mfma_f32_16x16x32_bf16; a wave owns all 64 out channels x in-channel quarter lw (the split of conv_wgrad9q_kernel).
+  // (A 32x32x16 form of this walk - out half x in half per wave, the transposing reads hidden in the 24 issue cycles
+  // that shape leaves free - needed 5 % fewer cycles per tile and ran 6 % slower: the chip clocks lower under that shape.)
+  f32x4 acc16[9][4];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc16[i][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one pixel tile: the matrix walk of conv_wgrad9q_kernel over halo rows
+  auto multiply = [&](const unsigned char* x_lds) __attribute__((always_inline)) {
+    // the multiplying wave outranks its SIMD partner, which is issuing copies: an MFMA leaves half of its issue
+    // cycles to other vector instructions, enough for the partner's address arithmetic
+    __builtin_amdgcn_s_setprio(W9P_PRIO);
+    // transposing-read lane geometry of conv_wgrad9q_kernel (16x16x32, quarter-wave split), rebuilt per tile from an
+    // opaque copy of the lane id: eight pointers that would otherwise stay live (and spill) across the staging phases
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int grp16 = ln >> 4, gq = (ln >> 2) & 3, gp = ln & 3;
+    const int cb0 = grp16 * 8 + gq;
+    const unsigned char* abase[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ach = h * 32 + 4 * gp;
+      abase[h] = dy_lds + cb0 * 128 + (((ach >> 3) ^ (((cb0 >> 1) & 1) << 2)) * 16) + (ach & 7) * 2;
+    }
+    const unsigned char* bb[3][2];      // [kw][halo-row parity]
+    {
+      const int bch = lw * 16 + 4 * gp;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int sw = (((cb0 + kw) >> 1) & 1) << 2;
+        const unsigned boff = (unsigned)((cb0 + kw) * 128 + (((bch >> 3) ^ sw) * 16) + (bch & 7) * 2);
+        bb[kw][0] = x_lds + boff;
+        bb[kw][1] = x_lds + (boff ^ 64u);
+      }
+    }
+    // Fragments are kept as their two 8-byte transposing reads, so that ONE read can be placed behind each matrix
+    // instruction: this wave is alone on its SIMD's matrix pipe during its phase (its partner stages), and a matrix
+    // instruction leaves the SIMD only half of its 16 issue cycles - a burst of reads in front of a group of four would
+    // stall the pipe for its length (two co-resident multiplying waves, as in conv_wgrad9q_kernel, cover each other's
+    // bursts; here nobody does).
+    short4v alo[3][4], ahi[3][4], blo[2][3], bhi[2][3];
+    auto rd = [&](const unsigned char* p_) {
+      return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p_);
+    };
+    auto load_a_half = [&](int ks, int ob, int half) {
+      const int a_imm = ks * 32 * 128 + (ob & 1) * 32 + half * 512;
+      if (half == 0) alo[ks % 3][ob] = rd(abase[ob >> 1] + a_imm);
+      else ahi[ks % 3][ob] = rd(abase[ob >> 1] + a_imm);
+    };
+    auto load_b_half = [&](int rho, int kw, int half) {
+      const int b_imm = rho * G::HWd * 128 + half * 512;
+      if (half == 0) blo[rho & 1][kw] = rd(bb[kw][rho & 1] + b_imm);
+      else bhi[rho & 1][kw] = rd(bb[kw][rho & 1] + b_imm);
+    };
+    auto frag = [&](const short4v& lo, const short4v& hi) {
+      short8v v;
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+      v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      return __builtin_bit_cast(bf16x8, v);
+    };
+#pragma unroll
+    for (int h = 0; h < 8; ++h) load_a_half(0, h >> 1, h & 1);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) load_b_half(0, h >> 1, h & 1);
+#pragma unroll
+    for (int rho = 0; rho < 10; ++rho) {
+      // this halo row's matrix instructions ("slots"), in the order kh = 2, 1, 0 (the oldest k-step first: its A slot is
+      // the one the next k-step's fragments go to, so those reads start behind the kh = 2 groups)
+      const int nkh2 = (rho >= 2 && rho - 2 < 8) ? 12 : 0;
+      const int nkh1 = (rho >= 1 && rho - 1 < 8) ? 12 : 0;
+      const int nslots = nkh2 + nkh1 + (rho < 8 ? 12 : 0);
+      const int nb = rho + 1 < 10 ? 6 : 0, na = rho + 1 < 8 ? 8 : 0;       // 8-byte reads to place in this row
+      // B read h goes behind slot h * sb, A read j behind slot nkh2 + j * sa (all inside the row for every rho)
+      const int sb = nb ? nslots / nb : 1, sa = na ? (nslots - nkh2) / na : 1;
+#pragma unroll
+      for (int kh = 2; kh >= 0; --kh) {
+        const int ks = rho - kh;
+        if (ks >= 0 && ks < 8) {
+          const int before = (kh < 2 ? nkh2 : 0) + (kh < 1 ? nkh1 : 0);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+              const int slot = before + kw * 4 + ob;
+              acc16[kh * 3 + kw][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(alo[ks % 3][ob], ahi[ks % 3][ob]),
+                                                                               frag(blo[rho & 1][kw], bhi[rho & 1][kw]),
+                                                                               acc16[kh * 3 + kw][ob], 0, 0, 0);
+              if (nb && slot % sb == 0 && slot / sb < nb) load_b_half(rho + 1, (slot / sb) >> 1, (slot / sb) & 1);
+              if (na && slot >= nkh2 && (slot - nkh2) % sa == 0 && (slot - nkh2) / sa < na)
+                load_a_half(rho + 1, ((slot - nkh2) / sa) >> 1, ((slot - nkh2) / sa) & 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // ---- prologue: the first x tile (group A's; both groups' when shared) and group A's first dy tile
+  if (shared) {
+    if (grp == 0) { w9p_stage_x<0, JXH>(a, xbuf, lw, lane, itA.t_begin, itA.cit); w9p_stage_dy(a, dy_lds, lw, lane, itA.t_begin, itA.cot); }
+    else w9p_stage_x<JXH, JX>(a, xbuf, lw, lane, itA.t_begin, itA.cit);
+  } else if (grp == 0 && itA.n > 0) {
+    w9p_stage_x<0, JX>(a, xbuf, lw, lane, itA.t_begin, itA.cit);
+    w9p_stage_dy(a, dy_lds, lw, lane, itA.t_begin, itA.cot);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#ifdef SNWS_TIMING
+  long long dbg[6] = {0, 0, 0, 0, 0, 0};
+#define W9P_T(v) const long long v = clock64()
+#else
+#define W9P_T(v)
+#endif
+  for (int k = 0; k < nloop; ++k) {
+    // ---- phase 2k: group A multiplies tile k; group B stages its tile k (and half of the shared x tile k + 1)
+    W9P_T(t0);
+    if (grp == 0) {
+      if (k < itA.n) multiply(xbuf + (shared ? (k & 1) * XB : 0));
+    } else if (!W9P_NOSTAGE) {
+      if (shared) {
+        if (k + 1 < nloop) w9p_stage_x<0, JXH>(a, xbuf + ((k + 1) & 1) * XB, lw, lane, itA.t_begin + k + 1, itA.cit);
+      } else if (k < itB.n) {
+        w9p_stage_x<0, JX>(a, xbuf + XB, lw, lane, itB.t_begin + k, itB.cit);
+      }
+      if (k < itB.n) w9p_stage_dy(a, dy_lds, lw, lane, itB.t_begin + k, itB.cot);
+      W9P_T(t1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SNWS_TIMING
+      dbg[2] += t1 - t0; dbg[3] += clock64() - t1;
+#endif
+    }
+    W9P_T(t2);
+    __syncthreads();
+    W9P_T(t3);
+#ifdef SNWS_TIMING
+    if (grp == 0) { dbg[0] += t2 - t0; dbg[1] += t3 - t2; } else dbg[4] += t3 - t2;
+#endif
+    // ---- phase 2k + 1: group B multiplies tile k; group A stages its tile k + 1
+    if (grp == 1) {
+      if (k < itB.n) multiply(xbuf + (shared ? (k & 1) * XB : XB));
+    } else if (!W9P_NOSTAGE) {
+      if (k + 1 < itA.n) {
+        if (shared) w9p_stage_x<JXH, JX>(a, xbuf + ((k + 1) & 1) * XB, lw, lane, itA.t_begin + k + 1, itA.cit);
+        else w9p_stage_x<0, JX>(a, xbuf, lw, lane, itA.t_begin + k + 1, itA.cit);
+        w9p_stage_dy(a, dy_lds, lw, lane, itA.t_begin + k + 1, itA.cot);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+#ifdef SNWS_TIMING
+    dbg[5] += clock64() - t3;
+#endif
+  }
+#ifdef SNWS_TIMING
+  if (tid == 0) {      // group A, wave 0: cycles multiplying, at the barrier behind it, whole second phase; tiles
+    atomicAdd(&snws_dbg[8], (unsigned long long)dbg[0]);
+    atomicAdd(&snws_dbg[9], (unsigned long long)dbg[1]);
+    atomicAdd(&snws_dbg[14], (unsigned long long)dbg[5]);
+    atomicAdd(&snws_dbg[13], (unsigned long long)nloop);
+  }
+  if (tid == 256) {    // group B, wave 0: cycles issuing the copies, waiting for them, at the barrier
+    atomicAdd(&snws_dbg[10], (unsigned long long)dbg[2]);
+    atomicAdd(&snws_dbg[11], (unsigned long long)dbg[3]);
+    atomicAdd(&snws_dbg[12], (unsigned long long)dbg[4]);
+  }
+#endif
+
+  // ---- flush: the partial-tile layout [tap][ob][in block][j][in-channel half][lane] of conv_wgrad9q_kernel
+  if (me.n > 0) {
+    const int fl_half = lw >> 1, fl_cb0 = lw & 1;
+    if (a.part) {
+      float* o = a.part + ((int64_t)me.split * npairs + me.pair) * 36864 + fl_half * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[(((i * 4 + ob) * 2 + fl_cb0) * 4 + j) * 128] = acc16[i][ob][j];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int co = me.cot * 64 + ob * 16 + 4 * (lane >> 4) + j;
+            const int ci16 = me.cit * 64 + fl_half * 32 + fl_cb0 * 16 + (lane & 15);
+            if (ci16 < a.Cin && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + i) * a.Cin + ci16, acc16[i][ob][j]);
+          }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- host
 int check_mfma_desc(const snws_conv_desc* d, const char* fn) {
   SNWS_CHECK_ARG(d, "%s: desc is NULL", fn);
@@ -1846,6 +2183,37 @@ int launch_wgrad9q(const WgradArgs& a, unsigned grid, hipStream_t st) {
   return SNWS_OK;
 }
 
+// SNWS_WGRAD9_PP = 0 selects conv_wgrad9q_kernel (two independent workgroups per CU) instead of the ping-pong kernel
+bool wgrad9_pp() {
+  static const bool on = !(getenv("SNWS_WGRAD9_PP") && atoi(getenv("SNWS_WGRAD9_PP")) == 0);
+  return on;
+}
+
+int wgrad9_pp_min_pairs() {
+  static const int n = getenv("SNWS_WGRAD9_PP_MIN_PAIRS") ? atoi(getenv("SNWS_WGRAD9_PP_MIN_PAIRS")) : 8;
+  return n;
+}
+
+int launch_wgrad9p(const WgradArgs& a, unsigned items, hipStream_t st) {
+  using G = WgGeom<64, 9>;
+  constexpr int LDS = 2 * (((G::X_BYTES + 15) / 16) * 16) + 2 * G::DY_BYTES;
+  static_assert(LDS <= 160 * 1024, "the ping-pong wgrad needs both x buffers and both dy tiles in one CU's LDS");
+  static PerDeviceOnce once;
+  std::atomic<bool>* const attr_set = once.flag();
+  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9p_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SNWS_ERR_HIP;
+    }
+    if (attr_set) attr_set->store(true, std::memory_order_release);
+  }
+  conv_wgrad9p_kernel<<<(items + 1) / 2, 512, LDS, st>>>(a);
+  SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
+  return SNWS_OK;
+}
+
 template <bool BIAS, bool M16>
 int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
   using G = WgGeom<64, 9>;
@@ -1871,7 +2239,7 @@ int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
 extern "C" int snws_dbg_read(unsigned long long* out8) {
   hipDeviceSynchronize();
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(snws_dbg), sizeof(snws_dbg)) != hipSuccess) return -1;
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   return hipMemcpyToSymbol(HIP_SYMBOL(snws_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -2035,7 +2403,13 @@ int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void
     a.coTiles = p.coTiles; a.ciTiles = p.ciTiles; a.tilesPerSplit = p.tilesPerSplit;
     a.prio = conv_prio();
     if (p.kind == 4 || p.kind == 5) {
-      if (p.kind == 5 && wgrad9_qw()) {
+      // the ping-pong kernel from 8 channel-tile pairs up (measured on one box against conv_wgrad9q_kernel: +1 % on
+      // 320->320 @512^2 at 0.57x its HBM fetch, +2..11 % on 256->256 @128^2 ... 1024->1024 @32^2, -3..-7 % on the one- to
+      // four-pair launches, whose two groups cannot share an x tile)
+      if (p.kind == 5 && wgrad9_qw() && wgrad9_pp() && !dbias && p.npairs >= wgrad9_pp_min_pairs()) {
+        rc = launch_wgrad9p(a, grid, st);
+      }
+      else if (p.kind == 5 && wgrad9_qw()) {
         if (a.prio) rc = dbias ? launch_wgrad9q<true, true>(a, grid, st) : launch_wgrad9q<false, true>(a, grid, st);
         else rc = dbias ? launch_wgrad9q<true, false>(a, grid, st) : launch_wgrad9q<false, false>(a, grid, st);
       }

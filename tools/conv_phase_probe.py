@@ -17,7 +17,7 @@ lib = L.lib()
 if not hasattr(lib, "snws_dbg_read"):
     sys.exit("this probe needs the diagnostics build: rebuild csrc/conv_mfma.hip with -DSNWS_TIMING "
              "(make FLAGS=\"... -DSNWS_TIMING\"), run it, then rebuild the shipped library without the flag")
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 for cin, cout, S in ((320, 320, 512), (320, 320, 256), (64, 64, 512), (128, 128, 256), (512, 512, 64)):
     x = torch.randn(N, S, S, cin, device="cuda:0").to(torch.bfloat16)
     y = torch.empty(N, S, S, cout, device="cuda:0", dtype=torch.bfloat16)

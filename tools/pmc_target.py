@@ -25,7 +25,7 @@ if what in ("conv", "wgrad"):
         if what == "conv":
             ops.conv_forward(x, prep, conv.bias, want_stats=True)
         else:
-            ops.conv_backward(dy, prep, saved, conv.weight, False, True, True)
+            ops.conv_backward(dy, prep, saved, conv.weight, False, True, False)   # no bias gradient, as inside a Conv2dws -> SwitchNorm block
 elif what == "sn":
     blk = ConvSnRelu(64, 64).to(DEV).train()
     x = torch.randn(N, 512, 512, 64, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)

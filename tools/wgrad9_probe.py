@@ -19,7 +19,9 @@ for cin, cout, S in ((320, 320, 512), (320, 64, 512), (64, 64, 512), (320, 320, 
     x = torch.randn(N, S, S, cin, device="cuda:0").to(torch.bfloat16)
     dy = torch.randn(N, S, S, cout, device="cuda:0").to(torch.bfloat16)
     g = torch.zeros(cout, 3, 3, cin, device="cuda:0")
-    db = torch.zeros(cout, device="cuda:0")
+    # no bias gradient, as in the training step (inside a Conv2dws -> SwitchNorm block it comes from the SwitchNorm
+    # backward in closed form); SNWS_PROBE_BIAS=1 asks for it
+    db = torch.zeros(cout, device="cuda:0") if os.environ.get("SNWS_PROBE_BIAS") == "1" else None
     cfg = ops.ConvCfg((cout, cin, 3, 3), 1, 1, 1, 1)
     d = cfg.desc(N, S, S, cin, cin, cout)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -28,10 +30,10 @@ for cin, cout, S in ((320, 320, 512), (320, 64, 512), (64, 64, 512), (320, 320, 
     ws = torch.empty(nbytes // 4, device="cuda:0")
 
     def run_atomic():
-        L.call("snws_conv_mfma_wgrad", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), db.data_ptr(), st)
+        L.call("snws_conv_mfma_wgrad", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), db.data_ptr() if db is not None else None, st)
 
     def run_det():      # partial tiles + fixed-order reduction (both kernels are inside the timed region)
-        L.call("snws_conv_mfma_wgrad_det", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), db.data_ptr(),
+        L.call("snws_conv_mfma_wgrad_det", ctypes.byref(d), x.data_ptr(), dy.data_ptr(), g.data_ptr(), db.data_ptr() if db is not None else None,
                ws.data_ptr(), nbytes, st)
     res = []
     for run in (run_atomic, run_det):
