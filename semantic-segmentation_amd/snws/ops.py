@@ -904,6 +904,8 @@ def sn_backward_pass2(s, p1, want_dx_sum=False, dx_sum_key=None, dres_dtype=None
            _ptr(dmw), _ptr(dvw), _ptr(dxsum), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), acc_b, st)
     if apply_fn is not None:
         dx = apply_fn(ctxb)
+        if want_dx_sum:
+            return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw), grad_fold(dxsum)
         return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw)
     dt = dtype_code(dys)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
@@ -1292,10 +1294,14 @@ class ConvSnReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
-        dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn)
-        ctx.sn = None
+        # the gradient of a bias added right in front of the normalisation is the per-channel sum of dconv, which the
+        # SwitchNorm backward has in closed form: the weight-gradient kernel need not sum the gradient tile's columns
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        res = sn_backward(dy, ctx.sn, want_dx_sum=nb, dx_sum_key=ctx.bias_key)
+        dconv, dg, dbeta, dmw, dvw = res[:5]
+        ctx.sn = None
+        dx, dw, _ = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, False, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        db = res[5] if nb else None
         ctx.in_segs = ctx.gslot = None
         ctx.saved = None
         if dw is not None:
@@ -1383,10 +1389,12 @@ class ConvSnReluHeadFn(torch.autograd.Function):
             _launch("sn_head_bwd_apply", 2.0 * N * HW * (2 * C + 16), "snws_sn_head_bwd_apply", _ptr(dls), _ptr(xs), ldx,
                     _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]), _ptr(hw16), _ptr(dx), C, N, HW, C, 1, st)
             return dx
-        dconv, dg, dbeta, dmw, dvw = sn_backward_pass2(s, p1, apply_fn=apply_fn)
-        ctx.sn = None
         nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        res = sn_backward_pass2(s, p1, want_dx_sum=nb, dx_sum_key=ctx.bias_key, apply_fn=apply_fn)
+        dconv, dg, dbeta, dmw, dvw = res[:5]
+        ctx.sn = None
+        dx, dw, _ = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, False, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        db = res[5] if nb else None
         ctx.in_segs = ctx.gslot = None
         ctx.saved = None
         if dw is not None:
@@ -1419,13 +1427,15 @@ class ConvSnAddReluFn(torch.autograd.Function):
         (weight,) = ctx.saved_tensors
         y = ctx.sn["y"]
         want_res = ctx.needs_input_grad[9]
-        dconv, dg, dbeta, dmw, dvw = sn_backward(dy, ctx.sn, dres_dtype=ctx.res_dtype if want_res else None)
+        nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        res = sn_backward(dy, ctx.sn, want_dx_sum=nb, dx_sum_key=ctx.bias_key, dres_dtype=ctx.res_dtype if want_res else None)
+        dconv, dg, dbeta, dmw, dvw = res[:5]
         dres = ctx.sn.pop("dres", None)
         if want_res and dres is None:
             dres = torch.where(y > 0, dy.to(y.dtype), torch.zeros((), dtype=y.dtype, device=y.device)).to(ctx.res_dtype)
         ctx.sn = None
-        nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx, dw, db = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        dx, dw, _ = conv_backward(dconv, ctx.prep, ctx.saved, weight, nx, nw, False, ctx.bias_key, ctx.in_segs, ctx.gslot)
+        db = res[5] if nb else None
         ctx.in_segs = ctx.gslot = None
         ctx.saved = None
         if dw is not None:
