@@ -295,6 +295,26 @@ int snws_ocr_attend_bwd(const void* q, int64_t ldq, const void* dout, int64_t ld
                         int64_t lddq, float* dkey_part, float* dval_part, int B, int64_t HW, int C, int K, float scale,
                         void* stream);
 
+/* The same two attention steps in float32, for any channel count and up to 64 classes - the float32 parity tier of
+ * UNet3p_res_ocr_SNws (the reference computes them with F.softmax + torch.matmul in float32,
+ * modeling/UNet3p_res_ocr_SNws.py:26-27,93-98).  Plain f32 vector arithmetic, fixed-order reductions.  All pixel tensors
+ * (B, HW, channels) float32 with a pixel stride; class scores (B, HW, K) with stride ldp; region tensors (B, K, C) dense.
+ *   snws_ocr32_gather_fwd: stat [B][K][2] (max, sum exp) and ctx [B][K][C]
+ *   snws_ocr32_gather_bwd: dfeats (+= when accumulate) and dprobs (B, HW, K) with stride lddp, dot[b][k] = <ctx, dctx>
+ *   snws_ocr32_attend_fwd / _bwd: key, val [B][K][C]; dkey_part / dval_part [B][snws_ocr32_runs(HW)][K][C], to be summed
+ *   over the runs (snws_partial_sum_batched). */
+int snws_ocr32_runs(int64_t HW);
+int snws_ocr32_gather_fwd(const float* feats, int64_t ldf, const float* probs, int64_t ldp, float* stat, float* ctx, int B,
+                          int64_t HW, int C, int K, float scale, void* stream);
+int snws_ocr32_gather_bwd(const float* feats, int64_t ldf, const float* probs, int64_t ldp, const float* stat,
+                          const float* dctx, const float* dot, float* dfeats, int64_t lddf, float* dprobs, int64_t lddp, int B,
+                          int64_t HW, int C, int K, float scale, int accumulate, void* stream);
+int snws_ocr32_attend_fwd(const float* q, int64_t ldq, const float* key, const float* val, float* out, int64_t ldo, int B,
+                          int64_t HW, int C, int K, float scale, void* stream);
+int snws_ocr32_attend_bwd(const float* q, int64_t ldq, const float* dout, int64_t lddo, const float* key, const float* val,
+                          float* dq, int64_t lddq, float* dkey_part, float* dval_part, int B, int64_t HW, int C, int K,
+                          float scale, void* stream);
+
 /* The last block of the network fused with the classification head - SwitchNorm + ReLU of the final convolution
  * (modeling/snorm.py:41-81, modeling/UNet3p_SNws.py:29-33) followed by the 1x1 nn.Conv2d head
  * (modeling/UNet3p_SNws.py:93,158; modeling/UNet_SNws.py:93,151) and their autograd - without storing the normalised

@@ -2190,7 +2190,7 @@ bool wgrad9_pp() {
 }
 
 int wgrad9_pp_min_pairs() {
-  static const int n = getenv("SNWS_WGRAD9_PP_MIN_PAIRS") ? atoi(getenv("SNWS_WGRAD9_PP_MIN_PAIRS")) : 8;
+  static const int n = getenv("SNWS_WGRAD9_PP_MIN_PAIRS") ? atoi(getenv("SNWS_WGRAD9_PP_MIN_PAIRS")) : 4;
   return n;
 }
 
@@ -2403,7 +2403,7 @@ int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void
     a.coTiles = p.coTiles; a.ciTiles = p.ciTiles; a.tilesPerSplit = p.tilesPerSplit;
     a.prio = conv_prio();
     if (p.kind == 4 || p.kind == 5) {
-      // the ping-pong kernel from 8 channel-tile pairs up (measured on one box against conv_wgrad9q_kernel: +1 % on
+      // the ping-pong kernel from 4 channel-tile pairs up (measured on one box against conv_wgrad9q_kernel: +1 % on
       // 320->320 @512^2 at 0.57x its HBM fetch, +2..11 % on 256->256 @128^2 ... 1024->1024 @32^2, -3..-7 % on the one- to
       // four-pair launches, whose two groups cannot share an x tile)
       if (p.kind == 5 && wgrad9_qw() && wgrad9_pp() && !dbias && p.npairs >= wgrad9_pp_min_pairs()) {

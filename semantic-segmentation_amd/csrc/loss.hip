@@ -17,7 +17,9 @@ __device__ __forceinline__ float ld1(const T* p) { return (float)(*p); }
 // (fixed summation order: bit-reproducible); dlogits = w[target] * (softmax - onehot) * scale for them, 0 for ignored
 // pixels and for the padding channels C..c_write-1.  w = class_weight (nn.CrossEntropyLoss(weight=...),
 // utils/loss.py:148) or 1 when NULL; a label outside [0, C) that is not ignore_index weighs 0.
-template <typename T, int V>
+// MAXC: compile-time bound of the class loops (16 for the usual <= 16 classes: a quarter of the predicated
+// instructions of the general 64-class form, which made the pass instruction-bound at 2 TB/s)
+template <typename T, int V, int MAXC>
 __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ logits, int64_t ld, const float* __restrict__ target,
                                                         int64_t npix, int C, int ignore_index, const float* __restrict__ scale_ptr,
                                                         const float* __restrict__ class_weight,
@@ -28,10 +30,10 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ lo
   float acc = 0.f;
   for (int64_t p = (int64_t)blockIdx.x * CE_THREADS + threadIdx.x; p < npix; p += (int64_t)gridDim.x * CE_THREADS) {
     const T* row = logits + p * ld;
-    float v[CE_MAX_C];
+    float v[MAXC];
     if (V == 8) {
 #pragma unroll
-      for (int c0 = 0; c0 < CE_MAX_C; c0 += 8) {
+      for (int c0 = 0; c0 < MAXC; c0 += 8) {
         if (c0 < C) {
           float f[8];
           Vec<T, V>::load(row + c0, *reinterpret_cast<float(*)[V]>(f));
@@ -41,12 +43,12 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ lo
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < CE_MAX_C; ++c)
+      for (int c = 0; c < MAXC; ++c)
         if (c < C) v[c] = ld1(row + c);
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < CE_MAX_C; ++c)
+    for (int c = 0; c < MAXC; ++c)
       if (c < C) m = fmaxf(m, v[c]);
     const float tf = target[p];
     const int t = (int)tf;                       // .long(): truncation toward zero
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ lo
     const float scale = scale0 * wt;
     float s = 0.f, gap = 0.f;                    // gap = logit[t] - max, taken BEFORE exponentiating: exp(gap) may underflow
 #pragma unroll
-    for (int c = 0; c < CE_MAX_C; ++c)
+    for (int c = 0; c < MAXC; ++c)
       if (c < C) {
         const float d = v[c] - m;
         if (c == t) gap = d;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ lo
       T* drow = dlogits + p * ldd;
       if (V == 8) {
 #pragma unroll
-        for (int c0 = 0; c0 < CE_MAX_C; c0 += 8) {
+        for (int c0 = 0; c0 < MAXC; c0 += 8) {
           if (c0 < c_write) {
             float f[8];
 #pragma unroll
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const T* __restrict__ lo
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < CE_MAX_C; ++c)
+        for (int c = 0; c < MAXC; ++c)
           if (c < c_write) drow[c] = (T)((c < C) ? v[c] * k - ((valid && c == t) ? scale : 0.f) : 0.f);
       }
     }
@@ -132,17 +134,20 @@ extern "C" int snws_ce_fwd_bwd_w(const void* logits, int dtype, int64_t ld, cons
   const bool vec = dtype == SNWS_BF16 && ld % 8 == 0 && ((uintptr_t)logits & 15) == 0 &&
                    (!dlogits || (ldd % 8 == 0 && c_write % 8 == 0 && ((uintptr_t)dlogits & 15) == 0)) &&
                    ((C + 7) / 8) * 8 <= ld;
+#define CE_LAUNCH(T, V, MAXC)                                                                                       \
+  ce_kernel<T, V, MAXC><<<grid, CE_THREADS, 0, st>>>((const T*)logits, ld, target, n_pixels, C, ignore_index, scale,  \
+                                                     class_weight, loss_part, (T*)dlogits, ldd, c_write)
+  const bool small = C <= 16 && (!dlogits || c_write <= 16);
   if (dtype == SNWS_BF16) {
-    if (vec)
-      ce_kernel<bf16_t, 8><<<grid, CE_THREADS, 0, st>>>((const bf16_t*)logits, ld, target, n_pixels, C, ignore_index, scale,
-                                                        class_weight, loss_part, (bf16_t*)dlogits, ldd, c_write);
-    else
-      ce_kernel<bf16_t, 1><<<grid, CE_THREADS, 0, st>>>((const bf16_t*)logits, ld, target, n_pixels, C, ignore_index, scale,
-                                                        class_weight, loss_part, (bf16_t*)dlogits, ldd, c_write);
+    if (vec && small) CE_LAUNCH(bf16_t, 8, 16);
+    else if (vec) CE_LAUNCH(bf16_t, 8, 64);
+    else if (small) CE_LAUNCH(bf16_t, 1, 16);
+    else CE_LAUNCH(bf16_t, 1, 64);
   } else {
-    ce_kernel<float, 1><<<grid, CE_THREADS, 0, st>>>((const float*)logits, ld, target, n_pixels, C, ignore_index, scale,
-                                                     class_weight, loss_part, (float*)dlogits, ldd, c_write);
+    if (small) CE_LAUNCH(float, 1, 16);
+    else CE_LAUNCH(float, 1, 64);
   }
+#undef CE_LAUNCH
   SNWS_LAUNCH_CHECK("snws_ce_fwd_bwd");
   return SNWS_OK;
 }

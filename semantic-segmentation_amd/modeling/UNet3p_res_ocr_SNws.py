@@ -6,8 +6,9 @@ What runs where: every Conv2dws -> SwitchNorm2d -> ReLU block, the residual bloc
 the full-scale skip decoder and all plain nn.Conv2d layers (1x1 and the 320 -> 512 3x3) go through the library's
 HIP kernels, and so do the OCR head's BatchNorm2d + ReLU pairs (blocks.HipBatchNorm2d; statistics of the local
 batch, as under the reference's DataParallel) and, in the bf16 tier, its two soft-max + batched-matmul attention
-steps (ops.OcrGatherFn / ops.OcrAttendFn); the Dropout2d after the last BatchNorm2d + ReLU rides on that pass's
-coefficients (HipBatchNorm2d.with_dropout).  The float32 tier's attention is stock torch.
+steps (ops.OcrGatherFn / ops.OcrAttendFn; ops.OcrGather32Fn / ops.OcrAttend32Fn in the float32 tier); the Dropout2d after the
+last BatchNorm2d + ReLU rides on that pass's coefficients (HipBatchNorm2d.with_dropout).  No attention step falls back
+to stock torch ops: unsupported inputs raise.
 """
 import torch
 import torch.nn as nn
@@ -23,12 +24,6 @@ from modeling.blocks import (ConvSnRelu, FusedAway, HipBatchNorm2d, PlainConv2d,
 from snws import ops
 
 
-def _pixels(x):
-    """(B,C,H,W) channels-last -> (B, H*W, C) without a copy."""
-    B, C, H, W = x.shape
-    return x.permute(0, 2, 3, 1).reshape(B, H * W, C)
-
-
 class SpatialGather_Module(nn.Module):
     """Soft object regions: class-probability-weighted average of the pixel features
     (modeling/UNet3p_res_ocr_SNws.py:10-28).  The soft-max over pixels runs in float32."""
@@ -42,9 +37,11 @@ class SpatialGather_Module(nn.Module):
         B, K = probs.size(0), probs.size(1)
         if ops.ocr_gather_ok(feats, probs):
             return ops.OcrGatherFn.apply(feats, probs, float(self.scale))               # B x C x K x 1
-        p = F.softmax(self.scale * probs.float().reshape(B, K, -1), dim=2)              # B x K x HW
-        ctx = torch.matmul(p.to(feats.dtype), _pixels(feats))                           # B x K x C
-        return ctx.permute(0, 2, 1).unsqueeze(3)                                        # B x C x K x 1
+        if ops.ocr32_ok(feats, K):
+            return ops.OcrGather32Fn.apply(feats, probs.float(), float(self.scale))
+        raise RuntimeError("SpatialGather_Module runs on the HIP kernels only: bf16 features with %d channels and <= 16 "
+                           "classes, or float32 GPU tensors with <= 64 classes (got %s %s, %d classes)"
+                           % (ops.OCR_GATHER_C, feats.dtype, tuple(feats.shape), K))
 
 
 class _ObjectAttentionBlock(nn.Module):
@@ -77,14 +74,11 @@ class _ObjectAttentionBlock(nn.Module):
             if self.scale > 1:
                 context = F.interpolate(input=context, size=(h, w), mode='bilinear', align_corners=True)
             return context
-        query = _pixels(q4)                                                              # B x HW x key
-        key = self.f_object(proxy).reshape(B, self.key_channels, -1)                     # B x key x K
-        value = _pixels(self.f_down(proxy))                                              # B x K x key
-        # attention logits in float32: a bf16 result would carry ~0.4 % of |logit| into the soft-max exponent
-        sim = torch.matmul(query.float(), key.float()) * (self.key_channels ** -.5)
-        sim = F.softmax(sim, dim=-1).to(query.dtype)                                     # B x HW x K
-        context = torch.matmul(sim, value)                                               # B x HW x key
-        context = context.reshape(B, x.size(2), x.size(3), self.key_channels).permute(0, 3, 1, 2)
+        if not ops.ocr32_ok(q4, proxy.shape[2]):
+            raise RuntimeError("_ObjectAttentionBlock runs on the HIP kernels only: bf16 queries with %d channels and <= 16 "
+                               "classes, or float32 GPU tensors with <= 64 classes (got %s %s, %d classes)"
+                               % (ops.OCR_ATTEND_C, q4.dtype, tuple(q4.shape), proxy.shape[2]))
+        context = ops.OcrAttend32Fn.apply(q4, self.f_object(proxy), self.f_down(proxy), self.key_channels ** -.5)
         context = self.f_up(context)
         if self.scale > 1:
             context = F.interpolate(input=context, size=(h, w), mode='bilinear', align_corners=True)

@@ -78,6 +78,12 @@ _SIGNATURES = {
     "snws_ocr_gather_bwd_acc": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int, c_int64, c_int, c_int, c_float, P]),
     "snws_ocr_attend_fwd": (c_int, [P, c_int64, P, P, P, c_int64, c_int, c_int64, c_int, c_int, c_float, P]),
     "snws_ocr_attend_bwd": (c_int, [P, c_int64, P, c_int64, P, P, P, c_int64, P, P, c_int, c_int64, c_int, c_int, c_float, P]),
+    "snws_ocr32_runs": (c_int, [c_int64]),
+    "snws_ocr32_gather_fwd": (c_int, [P, c_int64, P, c_int64, P, P, c_int, c_int64, c_int, c_int, c_float, P]),
+    "snws_ocr32_gather_bwd": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int64, c_int, c_int64, c_int, c_int,
+                                      c_float, c_int, P]),
+    "snws_ocr32_attend_fwd": (c_int, [P, c_int64, P, P, P, c_int64, c_int, c_int64, c_int, c_int, c_float, P]),
+    "snws_ocr32_attend_bwd": (c_int, [P, c_int64, P, c_int64, P, P, P, c_int64, P, P, c_int, c_int64, c_int, c_int, c_float, P]),
     "snws_sn_head_tiles": (c_int, [c_int64, c_int, c_int]),
     "snws_sn_apply_head": (c_int, [P, c_int64, P, P, P, P, P, c_int, c_int64, c_int, c_int, P]),
     "snws_sn_head_bwd_reduce": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int, c_int64, c_int, c_int, P]),
@@ -127,7 +133,7 @@ _SIGNATURES = {
 # entry points that return a status code (the others return a value)
 _STATUS = {k for k, (res, _) in _SIGNATURES.items() if res is c_int} - {
     "snws_version", "snws_conv_out_size", "snws_conv_mfma_tiles", "snws_sn_stats_tiles", "snws_ce_blocks",
-    "snws_upconv_stat_tiles", "snws_upconv_fwd_mode", "snws_upconv_bwd_mode", "snws_tile_minmax_blocks", "snws_conv_f32_tiles", "snws_sn_head_tiles", "snws_gemm1x1_supported", "snws_ocr_tiles"}
+    "snws_upconv_stat_tiles", "snws_upconv_fwd_mode", "snws_upconv_bwd_mode", "snws_tile_minmax_blocks", "snws_conv_f32_tiles", "snws_sn_head_tiles", "snws_gemm1x1_supported", "snws_ocr_tiles", "snws_ocr32_runs"}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1567,6 +1567,94 @@ class OcrAttendFn(torch.autograd.Function):
         return dq, _from_rows(dk, K, kdt), _from_rows(dv, K, vdt), None
 
 
+def ocr32_ok(t, n_class):
+    """Float32 pixel tensors on the GPU with at most 64 classes: the generic float32 attention kernels."""
+    return t.is_cuda and t.dtype == torch.float32 and n_class <= 64
+
+
+def _f32_nhwc(t):
+    """(B, C, H, W) float32 -> its NHWC view and pixel stride (a copy when the storage is not pixel-major)."""
+    ts, ld = as_nhwc(t if t.dtype == torch.float32 else t.float())
+    return ts, ld
+
+
+def _rows32(t, K):
+    """(B, C, K, 1) -> dense float32 (B, K, C)."""
+    B, C = t.shape[0], t.shape[1]
+    return t.detach().float().reshape(B, C, K).permute(0, 2, 1).contiguous()
+
+
+class OcrGather32Fn(torch.autograd.Function):
+    """OcrGatherFn in float32 (any channel count, K <= 64): snws_ocr32_gather_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, feats, probs, scale):
+        B, C, H, W = feats.shape
+        K, HW = probs.shape[1], H * W
+        fs, ldf = _f32_nhwc(feats)
+        ps, ldp = _f32_nhwc(probs)
+        stat = torch.empty((B, K, 2), dtype=torch.float32, device=feats.device)
+        c32 = torch.empty((B, K, C), dtype=torch.float32, device=feats.device)
+        _launch("ocr32_gather_fwd", 4.0 * B * HW * C, "snws_ocr32_gather_fwd", _ptr(fs), ldf, _ptr(ps), ldp, _ptr(stat), _ptr(c32),
+                B, HW, C, K, float(scale), _stream())
+        ctx.saved = (fs, ldf, ps, ldp, stat, c32, (B, C, H, W), K, float(scale))
+        ctx.gslot = grad_slot(feats)
+        return c32.permute(0, 2, 1).unsqueeze(3)                       # (B, C, K, 1)
+
+    @staticmethod
+    def backward(ctx, dctx):
+        fs, ldf, ps, ldp, stat, c32, (B, C, H, W), K, scale = ctx.saved
+        ctx.saved = None
+        d32 = _rows32(dctx, K)
+        dot = (c32 * d32).sum(-1).contiguous()
+        dprobs = new_nhwc(B, K, H, W, torch.float32, dctx.device)
+        dps, lddp = as_nhwc(dprobs)
+        slot, ctx.gslot = ctx.gslot, None
+        tgt = slot_buffer(slot, (B, C, H, W), torch.float32) if slot is not None else None
+        dfeats = tgt if tgt is not None else new_nhwc(B, C, H, W, torch.float32, dctx.device)
+        dfs, lddf = as_nhwc(dfeats)
+        _launch("ocr32_gather_bwd", 8.0 * B * H * W * C, "snws_ocr32_gather_bwd", _ptr(fs), ldf, _ptr(ps), ldp, _ptr(stat), _ptr(d32),
+                _ptr(dot), _ptr(dfs), lddf, _ptr(dps), lddp, B, H * W, C, K, scale, int(tgt is not None), _stream())
+        if tgt is not None:
+            return None, dprobs, None
+        return deliver_grad(slot, dfeats), dprobs, None
+
+
+class OcrAttend32Fn(torch.autograd.Function):
+    """OcrAttendFn in float32 (any channel count, K <= 64): snws_ocr32_attend_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, q, key, value, scale):
+        B, C, H, W = q.shape
+        K = key.shape[2]
+        qs, ldq = _f32_nhwc(q)
+        k32, v32 = _rows32(key, K), _rows32(value, K)
+        out = new_nhwc(B, C, H, W, torch.float32, q.device)
+        _launch("ocr32_attend_fwd", 8.0 * B * H * W * C, "snws_ocr32_attend_fwd", _ptr(qs), ldq, _ptr(k32), _ptr(v32), _ptr(out), C,
+                B, H * W, C, K, float(scale), _stream())
+        ctx.saved = (qs, ldq, k32, v32, (B, C, H, W), K, float(scale), key.dtype, value.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qs, ldq, k32, v32, (B, C, H, W), K, scale, kdt, vdt = ctx.saved
+        ctx.saved = None
+        lib, st, dev = L.lib(), _stream(), dout.device
+        ds, lddo = _f32_nhwc(dout)
+        runs = lib.snws_ocr32_runs(H * W)
+        dq = new_nhwc(B, C, H, W, torch.float32, dev)
+        dkp = torch.empty((B, runs, K, C), dtype=torch.float32, device=dev)
+        dvp = torch.empty((B, runs, K, C), dtype=torch.float32, device=dev)
+        _launch("ocr32_attend_bwd", 12.0 * B * H * W * C, "snws_ocr32_attend_bwd", _ptr(qs), ldq, _ptr(ds), lddo, _ptr(k32),
+                _ptr(v32), _ptr(dq), C, _ptr(dkp), _ptr(dvp), B, H * W, C, K, scale, st)
+        dk = torch.empty((B, K, C), dtype=torch.float32, device=dev)
+        dv = torch.empty((B, K, C), dtype=torch.float32, device=dev)
+        L.call("snws_partial_sum_batched", _ptr(dkp), B, runs, K * C, _ptr(dk), 0, st)
+        L.call("snws_partial_sum_batched", _ptr(dvp), B, runs, K * C, _ptr(dv), 0, st)
+        to4 = lambda m, dt: m.to(dt).permute(0, 2, 1).unsqueeze(3)       # noqa: E731   (B, K, C) -> (B, C, K, 1)
+        return dq, to4(dk, kdt), to4(dv, vdt), None
+
+
 # ------------------------------------------------------------------------------------------------ conv of an up-sampled map
 class PreparedTaps:
     """The standardized filter of a Conv2dws re-laid as a 1x1 filter with taps*O output channels (tap-major):

@@ -949,7 +949,7 @@ def test_res_ocr_bf16_vs_reference_run_with_bf16_storage():
     print("res-OCR bf16 vs reference with bf16 storage: logits %.4g (its rounding-flip noise %.4g, its own float32 gap %.4g; "
           "storage alone %.4g), vs float32 reference %.4g; loss %.6f vs %.6f; gradients (all, L2) %.4g (noise %.4g, "
           "float32 gap %.4g); per tensor: median %.4g (yardstick median %.4g)"
-          % (e_b, float(g["noise_logits"]), float(g["f32gap_logits"]), float(g["storage_logits"]), e_f, float(loss),
+          % (e_b, float(g["noise_logits"]), float(g["f32gap_logits"]), float(g["storage_logits"]), e_f, float(loss.detach()),
              float(g["loss_bf16"]), e_g, float(g["noise_grads_all"]), float(g["f32gap_grads_all"]),
              statistics.median(per), statistics.median(per_yard)))
     assert e_b < 2e-2

@@ -239,3 +239,59 @@ def test_batchnorm_relu_dropout2d_in_one_pass(dtype, tol):
     bn.eval()
     assert torch.equal(bn.with_dropout(x, torch.nn.Dropout2d(0.0).train()), bn(x))
     assert torch.equal(bn.with_dropout(x, drop.eval()), bn(x))
+
+
+@pytest.mark.parametrize("B,H,W,C,K", [(2, 20, 30, 512, 10), (1, 7, 9, 40, 3), (2, 33, 17, 100, 20)])
+def test_ocr_float32_kernels_vs_float64(B, H, W, C, K):
+    """The float32 tier's two attention steps (ops.OcrGather32Fn / ops.OcrAttend32Fn: any channel count, up to 64
+    classes) against the reference's arithmetic (F.softmax + torch.matmul, modeling/UNet3p_res_ocr_SNws.py:21-28,
+    87-100) in float64 on the same float32 inputs: forward and every gradient within 1e-5 (L2)."""
+    from snws import ops
+    torch.manual_seed(B * 1000 + C + K)
+    feats = torch.randn(B, H, W, C, device=DEV).permute(0, 3, 1, 2)
+    probs = (torch.randn(B, H, W, K, device=DEV) * 3).permute(0, 3, 1, 2)
+    dctx = torch.randn(B, C, K, 1, device=DEV)
+    f1, p1 = feats.detach().requires_grad_(True), probs.detach().requires_grad_(True)
+    assert ops.ocr32_ok(f1, K) and not ops.ocr_gather_ok(f1, p1)
+    out = ops.OcrGather32Fn.apply(f1, p1, 1.0)
+    assert out.shape == (B, C, K, 1) and out.dtype == torch.float32
+    out.backward(dctx)
+    f2, p2 = feats.detach().double().requires_grad_(True), probs.detach().double().requires_grad_(True)
+    pr = torch.softmax(p2.reshape(B, K, -1), dim=2)
+    ref = torch.matmul(pr, f2.permute(0, 2, 3, 1).reshape(B, H * W, C)).permute(0, 2, 1).unsqueeze(3)
+    ref.backward(dctx.double())
+    assert l2err(out, ref) < 1e-5
+    assert l2err(f1.grad, f2.grad) < 1e-5
+    assert l2err(p1.grad, p2.grad) < 1e-4          # differences of nearly equal sums: a few float32 ulps of the larger terms
+
+    q = torch.randn(B, H, W, C, device=DEV).permute(0, 3, 1, 2)
+    key = torch.randn(B, K, 1, C, device=DEV).permute(0, 3, 1, 2)
+    val = torch.randn(B, K, 1, C, device=DEV).permute(0, 3, 1, 2)
+    dout = torch.randn(B, H, W, C, device=DEV).permute(0, 3, 1, 2)
+    scale = C ** -0.5
+    a = [t.detach().requires_grad_(True) for t in (q, key, val)]
+    y = ops.OcrAttend32Fn.apply(a[0], a[1], a[2], scale)
+    y.backward(dout)
+    r = [t.detach().double().requires_grad_(True) for t in (q, key, val)]
+    query = r[0].permute(0, 2, 3, 1).reshape(B, H * W, C)
+    sim = torch.softmax(torch.matmul(query, r[1].reshape(B, C, K)) * scale, dim=-1)
+    ctx = torch.matmul(sim, r[2].reshape(B, C, K).permute(0, 2, 1))
+    yr = ctx.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    yr.backward(dout.double())
+    assert l2err(y, yr) < 1e-5
+    for got, want in zip(a, r):
+        assert l2err(got.grad, want.grad) < 1e-5
+    # deterministic: the same launch twice gives the same bits
+    a2 = [t.detach().requires_grad_(True) for t in (q, key, val)]
+    ops.OcrAttend32Fn.apply(a2[0], a2[1], a2[2], scale).backward(dout)
+    for u, v in zip(a, a2):
+        assert torch.equal(u.grad, v.grad)
+
+
+def test_ocr_modules_raise_on_unsupported_input():
+    """No attention step falls back to stock torch ops: inputs neither kernel family takes raise."""
+    from modeling.UNet3p_res_ocr_SNws import SpatialGather_Module
+    feats = torch.randn(1, 8, 4, 4, device=DEV, dtype=torch.float64)
+    probs = torch.randn(1, 3, 4, 4, device=DEV, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        SpatialGather_Module(3)(feats, probs)
