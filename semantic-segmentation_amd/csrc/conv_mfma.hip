@@ -25,7 +25,7 @@
 //   kernel a wave owns all 64 out channels x a 16-wide in-channel quarter x all nine taps and walks the halo rows, so
 //   one B fragment serves three taps.  The result leaves either as per-workgroup partial tiles that a fixed-order
 //   reduction sums (bit-reproducible; what the host modules use) or by float atomics into the f32 gradient.  3x3
-//   and 1x1 have their own kernels (conv_wgrad9q_kernel / conv_wgrad9_kernel, conv_wgrad1*_kernel); the generic one
+//   and 1x1 have their own kernels (conv_wgrad9p_kernel / conv_wgrad9q_kernel, conv_wgrad1*_kernel); the generic one
 //   serves C_in = 16.
 #include "common.h"
 #include "pack.h"
@@ -1223,23 +1223,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1t_kernel(Wgrad1wArgs a) {
 }
 
 // 3x3 wgrad over 64-wide in-channel tiles.  The generic kernel above reads one B fragment from LDS per MFMA, which
-// asks the LDS for its full 128 B/clk at the matrix pipe's peak rate.  Here a wave owns ALL 64 out channels (two A
-// fragments) x one 32-wide in-channel half x a group of 5 or 4 taps, so every B fragment feeds two MFMAs (7
-// fragment reads per 10 MFMAs instead of 10 per 9).  The 5/4 split alternates between co-resident workgroups so
-// the four SIMDs stay evenly loaded.  All LDS addresses are a per-lane base plus an immediate, and the fragments
-// of k-step s+1 are read while the MFMAs of step s run (two register sets).
-// M16: v_mfma_f32_16x16x32_bf16 (k-step = one 32-pixel tile row, 4 x 2 output blocks of 16 x 16 per tap) instead of
-// 32x32x16: the same fragment reads and matrix cycles per pixel, but the chip holds a higher clock under this shape.
-// QW (with M16): a wave owns all 64 out channels x one 16-wide in-channel QUARTER x all nine taps.  The B fragment of
-// (halo row rho, kw) then serves the three taps (kh, kw) at the k-steps rho - kh, so a tile needs 30 B fragments
-// instead of 72 (62 fragment reads per 288 matrix instructions instead of 100), and the four waves carry equal work.
+// asks the LDS for its full 128 B/clk at the matrix pipe's peak rate.  Here a wave owns all 64 out channels x one 16-wide
+// in-channel QUARTER x all nine taps (v_mfma_f32_16x16x32_bf16: a k-step is one 32-pixel tile row, 4 output blocks of
+// 16 x 16 per tap).  The B fragment of (halo row rho, kw) serves the three taps (kh, kw) at the k-steps rho - kh, so a
+// tile needs 30 B fragments and 32 A fragments for its 288 matrix instructions, and the four waves carry equal work.
 // The walk is over halo rows: A fragments of the three live k-steps sit in a rolling three-slot set, the next halo
-// row's B fragments and the next k-step's A fragments are read while the current row multiplies.
-template <bool FIVE, bool BIAS, bool M16, bool QW = false, bool PRIO = false>
+// row's B fragments and the next k-step's A fragments are read while the current row multiplies.  All LDS addresses are
+// a per-lane base plus an immediate.  (Retired after same-box measurements: a split by in-channel half x 5 / 4 taps,
+// which read 100 fragments per tile and loaded the waves unequally, and the 32x32x16 instruction shape, under which the
+// chip holds a lower clock.)
+template <bool BIAS, bool PRIO>
 __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* smem, int bid) {
-  static_assert(!QW || (M16 && FIVE), "the quarter-wave form exists for the 16x16x32 shape only");
   using G = WgGeom<64, 9>;
-  constexpr int NT = QW ? 9 : FIVE ? 5 : 4, T0 = (QW || FIVE) ? 0 : 5;
   unsigned char* dy_lds = smem;
   unsigned char* x_lds = smem + G::DY_BYTES;
 
@@ -1251,57 +1246,40 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   const int ntiles = a.N * a.tilesY * a.tilesX;
   const int t_begin = split * a.tilesPerSplit;
   const int t_end = t_begin + a.tilesPerSplit < ntiles ? t_begin + a.tilesPerSplit : ntiles;
-  const int ci_half = wave & 1;
   const bool want_bias = BIAS && cit == 0;
 
-  constexpr int NCB = QW ? 1 : 2;   // 16-wide in-channel blocks per wave
-  f32x16 acc[M16 ? 1 : NT][M16 ? 1 : 2];
-  f32x4 acc16[M16 ? NT : 1][M16 ? 4 : 1][M16 ? NCB : 1];    // [tap][out block of 16][in block of 16]
-  if constexpr (M16) {
+  f32x4 acc16[9][4];    // [tap][out block of 16]
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < 9; ++i)
 #pragma unroll
-      for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-        for (int cbk = 0; cbk < NCB; ++cbk) acc16[i][ob][cbk] = f32x4{0.f, 0.f, 0.f, 0.f};
-  } else {
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
-  }
+    for (int ob = 0; ob < 4; ++ob) acc16[i][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
   float* b_lds = reinterpret_cast<float*>(smem + G::DY_BYTES + ((G::X_BYTES + 15) / 16) * 16);   // [4 waves][64 channels]
   if (want_bias) b_lds[tid] = 0.f;   // ordered before its first use by the barrier that follows the first staging
 
   // transposing-read lane geometry (see the generic kernel): lane -> (channel group of 4, pixel within the k-step)
-  // (16x16x32: a 16-lane group reads the SAME 16 channels at the k octet 8 * group of a 32-pixel k-step)
+  // (a 16-lane group reads the SAME 16 channels at the k octet 8 * group of a 32-pixel k-step)
   const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
-  const int rb = M16 ? 0 : (grp & 1) * 16, kb = M16 ? grp * 8 : (grp >> 1) * 8;
-  const int cb0 = kb + gq;   // this lane's first pixel column inside a k-step; the second is cb0 + 4
+  const int cb0 = grp * 8 + gq;   // this lane's first pixel column inside a k-step; the second is cb0 + 4
   // dy tile: pixel p = row*32 + col; its chunk swizzle bit (p >> 1) & 1 only depends on cb0
-  // (16x16x32: abase[h] serves out blocks 2h and, 32 bytes further, 2h + 1)
+  // (abase[h] serves out blocks 2h and, 32 bytes further, 2h + 1)
   const unsigned char* abase[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int ach = h * 32 + rb + 4 * gp;
+    const int ach = h * 32 + 4 * gp;
     abase[h] = dy_lds + cb0 * 128 + (((ach >> 3) ^ (((cb0 >> 1) & 1) << 2)) * 16) + (ach & 7) * 2;
   }
   // x halo: pixel q = (row + kh)*34 + col + kw; swizzle bit (q >> 1) & 1 = (((cb0 + kw) >> 1) + row + kh) & 1, so an
   // odd tile row flips chunk bit 2 (byte-offset bit 6) relative to an even one
-  // (QW: one base per kw and halo-row parity, the halo row enters as an immediate)
-  constexpr int NBB = QW ? 3 : NT;
-  const unsigned char* bbase[NBB][2];
+  // (one base per kw and halo-row parity, the halo row enters as an immediate)
+  const unsigned char* bbase[3][2];
   {
-    const int bch = QW ? wave * 16 + 4 * gp : ci_half * 32 + rb + 4 * gp;
+    const int bch = wave * 16 + 4 * gp;
 #pragma unroll
-    for (int i = 0; i < NBB; ++i) {
-      const int kh = QW ? 0 : (T0 + i) / 3, kw = QW ? i : (T0 + i) % 3;
-      const int sw = ((((cb0 + kw) >> 1) + kh) & 1) << 2;
-      const int off = (kh * G::HWd + cb0 + kw) * 128 + (((bch >> 3) ^ sw) * 16) + (bch & 7) * 2;
-      bbase[i][0] = x_lds + off;
-      bbase[i][1] = x_lds + (off ^ 64);
+    for (int kw = 0; kw < 3; ++kw) {
+      const int sw = (((cb0 + kw) >> 1) & 1) << 2;
+      const int off = (cb0 + kw) * 128 + (((bch >> 3) ^ sw) * 16) + (bch & 7) * 2;
+      bbase[kw][0] = x_lds + off;
+      bbase[kw][1] = x_lds + (off ^ 64);
     }
   }
 
@@ -1412,112 +1390,55 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
       }
     }
 
-    if constexpr (QW) {
-      bf16x8 af[3][4], bq[2][3];
-      auto load_a1 = [&](int ks, int ob) {
-        const int a_imm = ks * 32 * 128 + (ob & 1) * 32;
-        af[ks % 3][ob] = tr_frag(abase[ob >> 1] + a_imm, abase[ob >> 1] + a_imm + 512);
-      };
-      auto load_b1 = [&](int rho, int kw) {
-        const int b_imm = rho * G::HWd * 128;
-        bq[rho & 1][kw] = tr_frag(bbase[kw][rho & 1] + b_imm, bbase[kw][rho & 1] + b_imm + 512);
-      };
+    {
+    bf16x8 af[3][4], bq[2][3];
+    auto load_a1 = [&](int ks, int ob) {
+      const int a_imm = ks * 32 * 128 + (ob & 1) * 32;
+      af[ks % 3][ob] = tr_frag(abase[ob >> 1] + a_imm, abase[ob >> 1] + a_imm + 512);
+    };
+    auto load_b1 = [&](int rho, int kw) {
+      const int b_imm = rho * G::HWd * 128;
+      bq[rho & 1][kw] = tr_frag(bbase[kw][rho & 1] + b_imm, bbase[kw][rho & 1] + b_imm + 512);
+    };
 #pragma unroll
-      for (int ob = 0; ob < 4; ++ob) load_a1(0, ob);
+    for (int ob = 0; ob < 4; ++ob) load_a1(0, ob);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) load_b1(0, kw);
+    for (int kw = 0; kw < 3; ++kw) load_b1(0, kw);
 #pragma unroll
-      for (int rho = 0; rho < 10; ++rho) {
-        // groups of this halo row in the order kh = 2, 1, 0 (the oldest k-step first: its A slot is refilled next)
-        const int nkh2 = (rho >= 2 && rho - 2 < 8) ? 3 : 0;
-        const int ngroups = ((rho >= 2 && rho - 2 < 8) ? 3 : 0) + ((rho >= 1 && rho - 1 < 8) ? 3 : 0) + (rho < 8 ? 3 : 0);
-        const bool want_a = rho + 1 < 8, want_b = rho + 1 < 10;
-        if constexpr (PRIO) {     // (compile-time: a branch here would cut the unrolled walk into blocks and spill)
-          if (rho == 0) __builtin_amdgcn_s_setprio(1);
-          if (rho == 4) __builtin_amdgcn_s_setprio(2);
-          if (rho == 7) __builtin_amdgcn_s_setprio(3);
-        }
-        const int a_per = (4 + (ngroups - nkh2) - 1) / (ngroups - nkh2 > 0 ? ngroups - nkh2 : 1);
-        int gi = 0, a_next = 0;
+    for (int rho = 0; rho < 10; ++rho) {
+      // groups of this halo row in the order kh = 2, 1, 0 (the oldest k-step first: its A slot is refilled next)
+      const int nkh2 = (rho >= 2 && rho - 2 < 8) ? 3 : 0;
+      const int ngroups = ((rho >= 2 && rho - 2 < 8) ? 3 : 0) + ((rho >= 1 && rho - 1 < 8) ? 3 : 0) + (rho < 8 ? 3 : 0);
+      const bool want_a = rho + 1 < 8, want_b = rho + 1 < 10;
+      if constexpr (PRIO) {     // (compile-time: a branch here would cut the unrolled walk into blocks and spill)
+        if (rho == 0) __builtin_amdgcn_s_setprio(1);
+        if (rho == 4) __builtin_amdgcn_s_setprio(2);
+        if (rho == 7) __builtin_amdgcn_s_setprio(3);
+      }
+      const int a_per = (4 + (ngroups - nkh2) - 1) / (ngroups - nkh2 > 0 ? ngroups - nkh2 : 1);
+      int gi = 0, a_next = 0;
 #pragma unroll
-        for (int kh = 2; kh >= 0; --kh) {
-          const int ks = rho - kh;
-          if (ks < 0 || ks >= 8) continue;
+      for (int kh = 2; kh >= 0; --kh) {
+        const int ks = rho - kh;
+        if (ks < 0 || ks >= 8) continue;
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            if (want_b && gi < 3) load_b1(rho + 1, gi);
-            if (want_a && gi >= nkh2) {
+        for (int kw = 0; kw < 3; ++kw) {
+          if (want_b && gi < 3) load_b1(rho + 1, gi);
+          if (want_a && gi >= nkh2) {
 #pragma unroll
-              for (int u = 0; u < a_per; ++u)
-                if (a_next < 4) { load_a1(rho + 1, a_next); ++a_next; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob)
-              acc16[kh * 3 + kw][ob][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks % 3][ob], bq[rho & 1][kw], acc16[kh * 3 + kw][ob][0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            ++gi;
+            for (int u = 0; u < a_per; ++u)
+              if (a_next < 4) { load_a1(rho + 1, a_next); ++a_next; }
           }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ob = 0; ob < 4; ++ob)
+            acc16[kh * 3 + kw][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks % 3][ob], bq[rho & 1][kw], acc16[kh * 3 + kw][ob], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          ++gi;
         }
       }
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    } else if constexpr (M16) {
-      // k-step = tile row (32 pixels).  Per (k-step, tap, in block) pair one B fragment feeds the four out blocks;
-      // the B fragment of pair f+2 and the A fragments of the next k-step are read while the MFMAs of pair f run.
-      // (in block 1 sits 32 bytes behind block 0: the chunk swizzle only touches chunk bit 2)
-      bf16x8 af[2][4], bq[3];
-      auto load_a = [&](int ks) {
-        const int a_imm = ks * 32 * 128;
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-          af[ks & 1][ob] = tr_frag(abase[ob >> 1] + a_imm + (ob & 1) * 32, abase[ob >> 1] + a_imm + (ob & 1) * 32 + 512);
-      };
-      auto load_b = [&](int f) {
-        const int ks = f / (2 * NT), i = (f / 2) % NT, cbk = f & 1;
-        const int b_imm = ks * G::HWd * 128 + cbk * 32;
-        bq[f % 3] = tr_frag(bbase[i][ks & 1] + b_imm, bbase[i][ks & 1] + b_imm + 512);
-      };
-      load_a(0);
-      load_b(0);
-      load_b(1);
-#pragma unroll
-      for (int f = 0; f < 8 * 2 * NT; ++f) {
-        const int ks = f / (2 * NT), i = (f / 2) % NT, cbk = f & 1;
-        if (f % (2 * NT) == 0 && ks + 1 < 8) load_a(ks + 1);
-        if (f + 2 < 8 * 2 * NT) load_b(f + 2);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-          acc16[i][ob][cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks & 1][ob], bq[f % 3], acc16[i][ob][cbk], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-    // flat software pipeline over (k-step, tap): the B fragment of pair f+2 and the A fragments of the next k-step
-    // are read while the MFMAs of pair f run
-    bf16x8 af[2][2], bq[3];
-    auto load_a = [&](int ks) {
-      const int a_imm = ((ks >> 1) * 32 + (ks & 1) * 16) * 128;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) af[ks & 1][h] = tr_frag(abase[h] + a_imm, abase[h] + a_imm + 512);
-    };
-    auto load_b = [&](int f) {
-      const int ks = f / NT, i = f % NT, row = ks >> 1;
-      const int b_imm = (row * G::HWd + (ks & 1) * 16) * 128;
-      bq[f % 3] = tr_frag(bbase[i][row & 1] + b_imm, bbase[i][row & 1] + b_imm + 512);
-    };
-    load_a(0);
-    load_b(0);
-    load_b(1);
-#pragma unroll
-    for (int f = 0; f < 16 * NT; ++f) {
-      const int ks = f / NT, i = f % NT;
-      if (i == 0 && ks + 1 < 16) load_a(ks + 1);
-      if (f + 2 < 16 * NT) load_b(f + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][0], bq[f % 3], acc[i][0], 0, 0, 0);
-      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][1], bq[f % 3], acc[i][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
 #ifdef SNWS_TIMING
@@ -1534,58 +1455,30 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
 #endif
 
   // ---- accumulate into the f32 gradient: D[row = out channel][col = in channel]
-  if constexpr (M16) {
-    // D[out channel 16 ob + 4 (lane >> 4) + j][in channel 32 half + 16 cbk + (lane & 15)]
-    // (QW: the wave's in-channel quarter is block (wave & 1) of half (wave >> 1) - the same partial-tile layout)
-    const int fl_half = QW ? wave >> 1 : ci_half, fl_cb0 = QW ? wave & 1 : 0;
-    if (a.part) {   // partial tile [tap][ob][cbk][j][in-channel half][lane]
+  // D[out channel 16 ob + 4 (lane >> 4) + j][in channel 16 wave + (lane & 15)]; the wave's in-channel quarter is block
+  // (wave & 1) of half (wave >> 1) in the partial-tile layout [tap][ob][in block][j][in-channel half][lane]
+  {
+    const int fl_half = wave >> 1, fl_cb0 = wave & 1;
+    if (a.part) {
       float* o = a.part + ((int64_t)split * npairs + pair) * 36864 + fl_half * 64 + lane;
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-          for (int cbk = 0; cbk < NCB; ++cbk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[((((T0 + i) * 4 + ob) * 2 + cbk + fl_cb0) * 4 + j) * 128] = acc16[i][ob][cbk][j];
+          for (int j = 0; j < 4; ++j) o[(((i * 4 + ob) * 2 + fl_cb0) * 4 + j) * 128] = acc16[i][ob][j];
     } else {
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-          for (int cbk = 0; cbk < NCB; ++cbk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int co = cot * 64 + ob * 16 + 4 * (lane >> 4) + j;
-              const int ci16 = cit * 64 + fl_half * 32 + (cbk + fl_cb0) * 16 + (lane & 15);
-              if (ci16 < a.Cin && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + (T0 + i)) * a.Cin + ci16, acc16[i][ob][cbk][j]);
-            }
+          for (int j = 0; j < 4; ++j) {
+            const int co = cot * 64 + ob * 16 + 4 * (lane >> 4) + j;
+            const int ci16 = cit * 64 + fl_half * 32 + fl_cb0 * 16 + (lane & 15);
+            if (ci16 < a.Cin && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + i) * a.Cin + ci16, acc16[i][ob][j]);
+          }
     }
-  } else {
-  const int ci = cit * 64 + ci_half * 32 + (lane & 31);
-  const bool ci_ok = ci < a.Cin;
-  if (a.part) {   // partial tile [tap][h][r][in-channel half][lane]: which wave holds a tap varies, the slot does not
-    float* o = a.part + ((int64_t)split * npairs + pair) * 36864 + ci_half * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[(((T0 + i) * 2 + h) * 16 + r) * 128] = acc[i][h][r];
-  } else {
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = cot * 64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (ci_ok && co < a.Cout) atomicAdd(a.dw + ((int64_t)co * 9 + (T0 + i)) * a.Cin + ci, acc[i][h][r]);
-        }
-      }
-    }
-  }
   }
   if (want_bias && tid < 64) {   // the loop's last barrier ordered every wave's partials
     const float v = b_lds[tid] + b_lds[tid + 64] + b_lds[tid + 128] + b_lds[tid + 192];
@@ -1594,20 +1487,10 @@ __device__ __forceinline__ void wgrad9_body(const WgradArgs& a, unsigned char* s
   }
 }
 
-template <bool BIAS, bool M16>
-__global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tg = __builtin_amdgcn_readfirstlane(((wave >> 1) ^ (bid >> 5)) & 1);
-  if (tg == 0) wgrad9_body<true, BIAS, M16>(a, smem, bid);
-  else wgrad9_body<false, BIAS, M16>(a, smem, bid);
-}
-
 template <bool BIAS, bool PRIO>
 __global__ __launch_bounds__(256, 2) void conv_wgrad9q_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  wgrad9_body<true, BIAS, true, true, PRIO>(a, smem, (int)xcd_remap(blockIdx.x, gridDim.x));
+  wgrad9_body<BIAS, PRIO>(a, smem, (int)xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // ------------------------------------------------------------------------------------------------- 3x3 wgrad, ping-pong
@@ -2132,12 +2015,6 @@ int launch_wgrad1w(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
   return SNWS_OK;
 }
 
-// SNWS_WGRAD_M16 = 0 selects the 32x32x16 form of the 3x3 wgrad kernel (A/B measurements); default: 16x16x32
-bool wgrad9_m16() {
-  static const bool on = !(getenv("SNWS_WGRAD_M16") && atoi(getenv("SNWS_WGRAD_M16")) == 0);
-  return on;
-}
-
 template <bool BIAS>
 int launch_wgrad1t(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
   using G = Wgrad1tGeom;
@@ -2155,13 +2032,6 @@ int launch_wgrad1t(const Wgrad1wArgs& a, unsigned grid, hipStream_t st) {
   conv_wgrad1t_kernel<BIAS><<<grid, 256, G::LDS_BYTES, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
   return SNWS_OK;
-}
-
-// SNWS_WGRAD9_QW = 0 selects the (in-channel half x tap group) wave split of the 16x16x32 3x3 wgrad kernel instead of
-// the (in-channel quarter x all taps) one (A/B measurements)
-bool wgrad9_qw() {
-  static const bool on = !(getenv("SNWS_WGRAD9_QW") && atoi(getenv("SNWS_WGRAD9_QW")) == 0);
-  return on;
 }
 
 template <bool BIAS, bool PRIO>
@@ -2210,25 +2080,6 @@ int launch_wgrad9p(const WgradArgs& a, unsigned items, hipStream_t st) {
     if (attr_set) attr_set->store(true, std::memory_order_release);
   }
   conv_wgrad9p_kernel<<<(items + 1) / 2, 512, LDS, st>>>(a);
-  SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
-  return SNWS_OK;
-}
-
-template <bool BIAS, bool M16>
-int launch_wgrad9(const WgradArgs& a, unsigned grid, hipStream_t st) {
-  using G = WgGeom<64, 9>;
-  static PerDeviceOnce once;
-  std::atomic<bool>* const attr_set = once.flag();
-  if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad9_kernel<BIAS, M16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    if (e != hipSuccess) {
-      snws_set_error("conv_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SNWS_ERR_HIP;
-    }
-    if (attr_set) attr_set->store(true, std::memory_order_release);
-  }
-  conv_wgrad9_kernel<BIAS, M16><<<grid, 256, G::LDS_BYTES, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_conv_mfma_wgrad");
   return SNWS_OK;
 }
@@ -2341,7 +2192,7 @@ WgradPlan wgrad_plan(const snws_conv_desc* d, bool det) {
     return p;
   }
   p.npairs = p.coTiles * p.ciTiles;
-  if (c64 && taps == 9 && !generic) { p.kind = wgrad9_m16() ? 5 : 4; p.E = 36864; }
+  if (c64 && taps == 9 && !generic) { p.kind = 5; p.E = 36864; }
   else if (c64 && taps == 1 && !generic) { p.kind = 2; p.E = 4096; }
   else { p.kind = c64 ? 0 : 1; p.E = taps * 4096; }
   // Atomic flush: every workgroup ends with a 64x64x9 float-atomic flush (147 KB; the chip retires ~1.3 TB/s of
@@ -2402,19 +2253,14 @@ int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void
     a.tilesX = cdiv(d->W, WG_TW); a.tilesY = cdiv(d->H, WG_TH);
     a.coTiles = p.coTiles; a.ciTiles = p.ciTiles; a.tilesPerSplit = p.tilesPerSplit;
     a.prio = conv_prio();
-    if (p.kind == 4 || p.kind == 5) {
+    if (p.kind == 5) {
       // the ping-pong kernel from 4 channel-tile pairs up (measured on one box against conv_wgrad9q_kernel: +1 % on
-      // 320->320 @512^2 at 0.57x its HBM fetch, +2..11 % on 256->256 @128^2 ... 1024->1024 @32^2, -3..-7 % on the one- to
-      // four-pair launches, whose two groups cannot share an x tile)
-      if (p.kind == 5 && wgrad9_qw() && wgrad9_pp() && !dbias && p.npairs >= wgrad9_pp_min_pairs()) {
-        rc = launch_wgrad9p(a, grid, st);
-      }
-      else if (p.kind == 5 && wgrad9_qw()) {
-        if (a.prio) rc = dbias ? launch_wgrad9q<true, true>(a, grid, st) : launch_wgrad9q<false, true>(a, grid, st);
-        else rc = dbias ? launch_wgrad9q<true, false>(a, grid, st) : launch_wgrad9q<false, false>(a, grid, st);
-      }
-      else if (p.kind == 5) rc = dbias ? launch_wgrad9<true, true>(a, grid, st) : launch_wgrad9<false, true>(a, grid, st);
-      else rc = dbias ? launch_wgrad9<true, false>(a, grid, st) : launch_wgrad9<false, false>(a, grid, st);
+      // 320->320 @512^2 at 0.57x its HBM fetch, +2..11 % on 256->256 @128^2 ... 1024->1024 @32^2, -3..-7 % on the one-
+      // and two-pair launches, whose two groups cannot share an x tile); a launch that wants the bias gradient (a
+      // Conv2dws outside a normalised block) takes conv_wgrad9q_kernel, which sums the staged gradient tile's columns
+      if (wgrad9_pp() && !dbias && p.npairs >= wgrad9_pp_min_pairs()) rc = launch_wgrad9p(a, grid, st);
+      else if (a.prio) rc = dbias ? launch_wgrad9q<true, true>(a, grid, st) : launch_wgrad9q<false, true>(a, grid, st);
+      else rc = dbias ? launch_wgrad9q<true, false>(a, grid, st) : launch_wgrad9q<false, false>(a, grid, st);
     }
     else if (p.kind == 2) rc = dbias ? launch_wgrad1<true>(a, grid, st) : launch_wgrad1<false>(a, grid, st);
     else if (p.kind == 0) rc = taps == 9 ? launch_wgrad<64, 9>(a, grid, st) : launch_wgrad<64, 1>(a, grid, st);

@@ -10,7 +10,7 @@ namespace {
 // dw (O, taps, Cin); the bias partials are summed the same way and ADDED to dbias by one thread per channel (no
 // atomics: kernels on a stream run one after the other, so the result is bit-reproducible).
 // kind: 0 generic 64-wide, 1 generic C_in = 16 (its two pixel-row halves hold partial sums of the same outputs),
-//       2 wgrad1, 3 wgrad1w, 4 / 5 wgrad9 (32x32x16 / 16x16x32 form), 6 wgrad1t - the register orders the kernels above store
+//       2 wgrad1, 3 wgrad1w, 5 wgrad9 (conv_wgrad9q_kernel and conv_wgrad9p_kernel), 6 wgrad1t - the register orders the kernels above store
 //       their tiles in.
 struct WgradReduceArgs {
   const float* part;
@@ -37,14 +37,6 @@ __device__ __forceinline__ bool wgrad_decode(int kind, int e, int cot, int cit, 
     tap = q >> 5;
     co = cot * 64 + ob * 16 + 4 * (lane >> 4) + j;
     ci = cit * 64 + cih * 32 + cbk * 16 + (lane & 15);
-    return true;
-  }
-  if (kind == 4) {          // [tap][h][r][in-channel half][lane]
-    const int lane = e & 63, cih = (e >> 6) & 1, q = e >> 7;
-    const int r = q & 15, h = (q >> 4) & 1;
-    tap = q >> 5;
-    co = cot * 64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    ci = cit * 64 + cih * 32 + (lane & 31);
     return true;
   }
   if (kind == 3) {          // [i][h][r][wave][lane], wave = (out quadrant, in quadrant)
