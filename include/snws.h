@@ -228,6 +228,69 @@ int snws_sn_bwd_apply_res(const void* dy, int64_t lddy, const void* x, int64_t l
                           void* dx, int64_t lddx, void* dres, int64_t lddres, int dtype, const float* ctx,
                           const float* ctxb, const float* beta, int N, int64_t HW, int C, void* stream);
 
+/* Batched forms: up to SNWS_SN_BATCH_MAX INDEPENDENT SwitchNorm calls of the same N, HW, C and dtype in one launch per
+ * pass - the branch blocks of a UNet3+ decoder scale (modeling/UNet3p_SNws.py:127-156: five ConvSnRelu blocks whose
+ * outputs meet only in the torch.cat that follows).  Item i is exactly the call of the single form with the item's
+ * pointers; the results are bit-identical to `count` single calls.  The calls of one launch must not share what they
+ * write: running buffers (snws_sn_mix_b_batched, training with using_bn) and gradient buffers (the backward forms) must
+ * differ between items, or SNWS_ERR_INVALID is returned - uses of ONE module belong to successive launches, in the
+ * module's call order.  The apply passes need 16-byte aligned tensors, pixel strides and channel counts
+ * (SNWS_ERR_UNSUPPORTED otherwise: fall back to the single calls).
+ *   forward : snws_sn_fwd_a_batched (= snws_sn_finalize + snws_sn_mix_a) -> [all-reduce of the packs]
+ *             -> snws_sn_mix_b_batched -> snws_sn_apply_batched (no residual)
+ *   backward: [snws_sn_bwd_reduce or a dgrad epilogue per item] -> snws_sn_bwd_a_batched (= snws_sn_bwd_mix_a)
+ *             -> [all-reduce of the packbs] -> snws_sn_bwd_mix_b_batched -> snws_sn_bwd_apply_batched (mask from x) */
+#define SNWS_SN_BATCH_MAX 8
+typedef struct snws_sn_fwd_item {
+  const float* part;   /* (N, T, C, 2) partial moments */
+  const float* shift;  /* (N, C) or (C) */
+  float* ctx;
+  float* pack;         /* 2C + 1 floats */
+  const float* gamma;
+  const float* beta;
+  const float* mean_weight;
+  const float* var_weight;
+  float* running_mean; /* nullable unless using_bn */
+  float* running_var;
+  const void* x;       /* apply pass only */
+  void* y;
+  int64_t ldx, ldy;
+  int T, shift_per_image;
+} snws_sn_fwd_item;
+typedef struct snws_sn_bwd_item {
+  const float* part;   /* (N, T, C, 2) partial sums of dy', dy' * xhat */
+  const float* ctx;
+  const float* gamma;
+  const float* beta;
+  const float* mean_weight;
+  const float* var_weight;
+  float* ctxb;
+  float* packb;        /* 2C floats */
+  float* dgamma;
+  float* dbeta;
+  float* dmean_weight;
+  float* dvar_weight;
+  float* dx_sum;       /* nullable */
+  const void* dy;      /* apply pass only */
+  const void* x;
+  void* dx;
+  int64_t lddy, ldx, lddx;
+  int T;
+  int accumulate_a;    /* `accumulate` of snws_sn_bwd_mix_a */
+  int accumulate_b;    /* `accumulate` of snws_sn_bwd_mix_b */
+  int reserved;
+} snws_sn_bwd_item;
+int snws_sn_fwd_a_batched(const snws_sn_fwd_item* items, int count, int N, int64_t HW, int C, void* stream);
+int snws_sn_mix_b_batched(const snws_sn_fwd_item* items, int count, int N, int C, float eps, float momentum,
+                          int training, int using_movavg, int using_bn, void* stream);
+int snws_sn_apply_batched(const snws_sn_fwd_item* items, int count, int dtype, int N, int64_t HW, int C, int relu,
+                          void* stream);
+int snws_sn_bwd_a_batched(const snws_sn_bwd_item* items, int count, int N, int C, void* stream);
+int snws_sn_bwd_mix_b_batched(const snws_sn_bwd_item* items, int count, int N, int64_t HW, int C, float n_global,
+                              int training, int using_bn, void* stream);
+int snws_sn_bwd_apply_batched(const snws_sn_bwd_item* items, int count, int dtype, int N, int64_t HW, int C, int relu,
+                              void* stream);
+
 /* SwitchNorm forward in one call that allocates nothing and takes no side buffers: snws_sn_stats -> snws_sn_finalize
  * -> snws_sn_mix_a -> snws_sn_mix_b -> snws_sn_apply with part / shift / ctx / pack held in a static device array of
  * the library (snws_sn_noalloc_max_floats() floats = 16 MiB, resident on every GPU the library runs on until the

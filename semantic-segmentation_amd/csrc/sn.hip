@@ -138,7 +138,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_stats_kernel(const T* __restric
 }
 
 // partial moments -> mean_in, var_in (unbiased)
-__global__ __launch_bounds__(512) void sn_finalize_kernel(const float* __restrict__ part, int T,
+__device__ __forceinline__ void sn_finalize_body(const float* __restrict__ part, int T,
                                                           const float* __restrict__ shift, int shift_per_image, int N,
                                                           int64_t HW, int C, float* __restrict__ ctx) {
   __shared__ double red[2][8][64];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void sn_finalize_kernel(const float* __restric
 }
 
 // LN moments per image, local BN sums per channel
-__global__ __launch_bounds__(256) void sn_mix_a_kernel(float* __restrict__ ctx, float* __restrict__ pack, int N, int C) {
+__device__ __forceinline__ void sn_mix_a_body(float* __restrict__ ctx, float* __restrict__ pack, int N, int C) {
   __shared__ double scratch[16];
   const CtxOff o = ctx_off(N, C);
   if ((int)blockIdx.x < N) {
@@ -229,7 +229,7 @@ __device__ __forceinline__ void softmax_k(const float* w, int K, float* out) {
   for (int i = 0; i < 3; ++i) out[i] = i < K ? e[i] / s : 0.f;
 }
 
-__global__ __launch_bounds__(256) void sn_mix_b_kernel(float* __restrict__ ctx, const float* __restrict__ pack,
+__device__ __forceinline__ void sn_mix_b_body(float* __restrict__ ctx, const float* __restrict__ pack,
                                                        const float* __restrict__ gamma, const float* __restrict__ mw,
                                                        const float* __restrict__ vw, float* __restrict__ rmean,
                                                        float* __restrict__ rvar, int N, int C, float eps, float momentum,
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void sn_mix_b_kernel(float* __restrict__ ctx, 
 
 // ------------------------------------------------------------------------------------------- pass 2: normalise
 template <typename T, int V, bool RELU, bool RES>
-__global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+__device__ __forceinline__ void sn_apply_body(const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
                                                               int64_t ldy, const T* __restrict__ res, int64_t ldr,
                                                               const float* __restrict__ ctx,
                                                               const float* __restrict__ beta, int N, int64_t HW, int C,
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_reduce_kernel(const T* __re
 }
 
 // partials -> P, Q, dm, dv per (n,c)
-__global__ __launch_bounds__(512) void sn_bwd_mix_a1_kernel(const float* __restrict__ part, int T,
+__device__ __forceinline__ void sn_bwd_mix_a1_body(const float* __restrict__ part, int T,
                                                             const float* __restrict__ ctx,
                                                             const float* __restrict__ gamma, float* __restrict__ ctxb,
                                                             int N, int C) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512) void sn_bwd_mix_a1_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void sn_bwd_mix_a2_kernel(float* __restrict__ ctxb, float* __restrict__ packb,
+__device__ __forceinline__ void sn_bwd_mix_a2_body(float* __restrict__ ctxb, float* __restrict__ packb,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
                                                             int C, int accumulate) {
   __shared__ double scratch[16];
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void sn_bwd_mix_a2_kernel(float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restrict__ ctx, float* __restrict__ ctxb,
+__device__ __forceinline__ void sn_bwd_mix_b_body(const float* __restrict__ ctx, float* __restrict__ ctxb,
                                                             const float* __restrict__ packb,
                                                             const float* __restrict__ mw, const float* __restrict__ vw,
                                                             float* __restrict__ dmw, float* __restrict__ dvw,
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------- backward pass 2
 // DRES: also store the masked incoming gradient (the gradient of a residual input added before the ReLU)
 template <typename T, int V, bool RELU, bool YMASK, bool DRES = false>
-__global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy,
+__device__ __forceinline__ void sn_bwd_apply_body(const T* __restrict__ dy, int64_t lddy,
                                                                   const T* __restrict__ x, int64_t ldx,
                                                                   const T* __restrict__ ym, int64_t ldy,
                                                                   T* __restrict__ dx, int64_t lddx,
@@ -763,6 +763,116 @@ __global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __res
       VecNT<T, V>::store(on + p * lddx + co, g0);
     }
   }
+}
+
+
+// ------------------------------------------------------------------------------------------- kernels
+// Every pass exists as a plain kernel and as a BATCHED kernel: up to SNWS_SN_BATCH_MAX independent SwitchNorm calls of
+// the same (N, HW, C, dtype) - the five branch blocks of a UNet3+ decoder scale - run as ONE launch per pass, the call
+// picked by blockIdx.z.  The per-(image, channel) passes are latency-bound (a few microseconds whatever their size), so
+// five calls cost what one does; the streaming passes save their ramps.
+__global__ __launch_bounds__(512) void sn_finalize_kernel(const float* __restrict__ part, int T,
+                                                          const float* __restrict__ shift, int shift_per_image, int N,
+                                                          int64_t HW, int C, float* __restrict__ ctx) {
+  sn_finalize_body(part, T, shift, shift_per_image, N, HW, C, ctx);
+}
+__global__ __launch_bounds__(256) void sn_mix_a_kernel(float* __restrict__ ctx, float* __restrict__ pack, int N, int C) {
+  sn_mix_a_body(ctx, pack, N, C);
+}
+__global__ __launch_bounds__(256) void sn_mix_b_kernel(float* __restrict__ ctx, const float* __restrict__ pack,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mw,
+                                                       const float* __restrict__ vw, float* __restrict__ rmean,
+                                                       float* __restrict__ rvar, int N, int C, float eps, float momentum,
+                                                       int training, int using_movavg, int using_bn) {
+  sn_mix_b_body(ctx, pack, gamma, mw, vw, rmean, rvar, N, C, eps, momentum, training, using_movavg, using_bn);
+}
+template <typename T, int V, bool RELU, bool RES>
+__global__ __launch_bounds__(SN_THREADS) void sn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                              int64_t ldy, const T* __restrict__ res, int64_t ldr,
+                                                              const float* __restrict__ ctx,
+                                                              const float* __restrict__ beta, int N, int64_t HW, int C,
+                                                              int PT, SnMap m, const float* __restrict__ post = nullptr) {
+  sn_apply_body<T, V, RELU, RES>(x, ldx, y, ldy, res, ldr, ctx, beta, N, HW, C, PT, m, post);
+}
+__global__ __launch_bounds__(512) void sn_bwd_mix_a1_kernel(const float* __restrict__ part, int T,
+                                                            const float* __restrict__ ctx,
+                                                            const float* __restrict__ gamma, float* __restrict__ ctxb,
+                                                            int N, int C) {
+  sn_bwd_mix_a1_body(part, T, ctx, gamma, ctxb, N, C);
+}
+__global__ __launch_bounds__(256) void sn_bwd_mix_a2_kernel(float* __restrict__ ctxb, float* __restrict__ packb,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                            int C, int accumulate) {
+  sn_bwd_mix_a2_body(ctxb, packb, dgamma, dbeta, N, C, accumulate);
+}
+__global__ __launch_bounds__(1024) void sn_bwd_mix_b_kernel(const float* __restrict__ ctx, float* __restrict__ ctxb,
+                                                            const float* __restrict__ packb,
+                                                            const float* __restrict__ mw, const float* __restrict__ vw,
+                                                            float* __restrict__ dmw, float* __restrict__ dvw,
+                                                            float* __restrict__ dxsum, int N, int64_t HW, int C,
+                                                            float Ng, int training, int using_bn, int accumulate) {
+  sn_bwd_mix_b_body(ctx, ctxb, packb, mw, vw, dmw, dvw, dxsum, N, HW, C, Ng, training, using_bn, accumulate);
+}
+template <typename T, int V, bool RELU, bool YMASK, bool DRES = false>
+__global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy,
+                                                                  const T* __restrict__ x, int64_t ldx,
+                                                                  const T* __restrict__ ym, int64_t ldy,
+                                                                  T* __restrict__ dx, int64_t lddx,
+                                                                  const float* __restrict__ ctx,
+                                                                  const float* __restrict__ ctxb,
+                                                                  const float* __restrict__ beta, int N, int64_t HW,
+                                                                  int C, int PT, SnMap m,
+                                                                  T* __restrict__ dres = nullptr, int64_t lddr = 0,
+                                                                  const float* __restrict__ post = nullptr) {
+  sn_bwd_apply_body<T, V, RELU, YMASK, DRES>(dy, lddy, x, ldx, ym, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, PT, m, dres,
+                                             lddr, post);
+}
+
+struct SnFwdBatch { snws_sn_fwd_item item[SNWS_SN_BATCH_MAX]; };
+struct SnBwdBatch { snws_sn_bwd_item item[SNWS_SN_BATCH_MAX]; };
+
+__global__ __launch_bounds__(512) void sn_finalize_batched_kernel(const SnFwdBatch b, int N, int64_t HW, int C) {
+  const snws_sn_fwd_item& d = b.item[blockIdx.z];
+  sn_finalize_body(d.part, d.T, d.shift, d.shift_per_image, N, HW, C, d.ctx);
+}
+__global__ __launch_bounds__(256) void sn_mix_a_batched_kernel(const SnFwdBatch b, int N, int C) {
+  const snws_sn_fwd_item& d = b.item[blockIdx.z];
+  sn_mix_a_body(d.ctx, d.pack, N, C);
+}
+__global__ __launch_bounds__(256) void sn_mix_b_batched_kernel(const SnFwdBatch b, int N, int C, float eps,
+                                                               float momentum, int training, int using_movavg,
+                                                               int using_bn) {
+  const snws_sn_fwd_item& d = b.item[blockIdx.z];
+  sn_mix_b_body(d.ctx, d.pack, d.gamma, d.mean_weight, d.var_weight, d.running_mean, d.running_var, N, C, eps, momentum,
+                training, using_movavg, using_bn);
+}
+template <typename T, int V, bool RELU>
+__global__ __launch_bounds__(SN_THREADS) void sn_apply_batched_kernel(const SnFwdBatch b, int N, int64_t HW, int C,
+                                                                      int PT, SnMap m) {
+  const snws_sn_fwd_item& d = b.item[blockIdx.z];
+  sn_apply_body<T, V, RELU, false>((const T*)d.x, d.ldx, (T*)d.y, d.ldy, nullptr, 0, d.ctx, d.beta, N, HW, C, PT, m,
+                                   nullptr);
+}
+__global__ __launch_bounds__(512) void sn_bwd_mix_a1_batched_kernel(const SnBwdBatch b, int N, int C) {
+  const snws_sn_bwd_item& d = b.item[blockIdx.z];
+  sn_bwd_mix_a1_body(d.part, d.T, d.ctx, d.gamma, d.ctxb, N, C);
+}
+__global__ __launch_bounds__(256) void sn_bwd_mix_a2_batched_kernel(const SnBwdBatch b, int N, int C) {
+  const snws_sn_bwd_item& d = b.item[blockIdx.z];
+  sn_bwd_mix_a2_body(d.ctxb, d.packb, d.dgamma, d.dbeta, N, C, d.accumulate_a);
+}
+__global__ __launch_bounds__(1024) void sn_bwd_mix_b_batched_kernel(const SnBwdBatch b, int N, int64_t HW, int C,
+                                                                    float Ng, int training, int using_bn) {
+  const snws_sn_bwd_item& d = b.item[blockIdx.z];
+  sn_bwd_mix_b_body(d.ctx, d.ctxb, d.packb, d.mean_weight, d.var_weight, d.dmean_weight, d.dvar_weight, d.dx_sum, N, HW,
+                    C, Ng, training, using_bn, d.accumulate_b);
+}
+template <typename T, int V, bool RELU>
+__global__ __launch_bounds__(SN_THREADS) void sn_bwd_apply_batched_kernel(const SnBwdBatch b, int N, int64_t HW, int C,
+                                                                          int PT, SnMap m) {
+  const snws_sn_bwd_item& d = b.item[blockIdx.z];
+  sn_bwd_apply_body<T, V, RELU, false, false>((const T*)d.dy, d.lddy, (const T*)d.x, d.ldx, nullptr, 0, (T*)d.dx, d.lddx,
+                                              d.ctx, d.ctxb, d.beta, N, HW, C, PT, m, nullptr, 0, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------- host side
@@ -1016,6 +1126,159 @@ extern "C" int snws_sn_bwd_apply_res(const void* dy, int64_t lddy, const void* x
   if (can_vec<bf16_t>(C, {dy, x, y_for_mask, dx, dres}, {lddy, ldx, ldy, lddx, lddres}))
     return run_bwd_apply<bf16_t, 8>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
   return run_bwd_apply<bf16_t, 1>(dy, lddy, x, ldx, y_for_mask, ldy, dx, lddx, ctx, ctxb, beta, N, HW, C, 1, st, dres, lddres);
+}
+
+// ------------------------------------------------------------------------------------------- batched passes
+namespace {
+template <typename Item>
+int copy_batch(const Item* items, int count, Item* dst, const char* fn) {
+  SNWS_CHECK_ARG(items && count >= 1 && count <= SNWS_SN_BATCH_MAX, "%s: count %d outside 1..%d (or NULL items)", fn, count,
+                 SNWS_SN_BATCH_MAX);
+  for (int i = 0; i < count; ++i) dst[i] = items[i];
+  for (int i = count; i < SNWS_SN_BATCH_MAX; ++i) dst[i] = items[0];
+  return SNWS_OK;
+}
+}  // namespace
+
+extern "C" int snws_sn_fwd_a_batched(const snws_sn_fwd_item* items, int count, int N, int64_t HW, int C, void* stream) {
+  SnFwdBatch b;
+  if (int rc = copy_batch(items, count, b.item, "snws_sn_fwd_a_batched")) return rc;
+  SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1, "snws_sn_fwd_a_batched: bad sizes");
+  for (int i = 0; i < count; ++i)
+    SNWS_CHECK_ARG(items[i].part && items[i].shift && items[i].ctx && items[i].pack && items[i].T >= 1,
+                   "snws_sn_fwd_a_batched: item %d: NULL pointer or T < 1", i);
+  hipStream_t st = (hipStream_t)stream;
+  sn_finalize_batched_kernel<<<dim3(cdiv(C, 64), N, count), 512, 0, st>>>(b, N, HW, C);
+  SNWS_LAUNCH_CHECK("snws_sn_fwd_a_batched(finalize)");
+  sn_mix_a_batched_kernel<<<dim3(N + cdiv(C, 256), 1, count), 256, 0, st>>>(b, N, C);
+  SNWS_LAUNCH_CHECK("snws_sn_fwd_a_batched(mix_a)");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_mix_b_batched(const snws_sn_fwd_item* items, int count, int N, int C, float eps, float momentum,
+                                     int training, int using_movavg, int using_bn, void* stream) {
+  SnFwdBatch b;
+  if (int rc = copy_batch(items, count, b.item, "snws_sn_mix_b_batched")) return rc;
+  SNWS_CHECK_ARG(N >= 1 && C >= 1, "snws_sn_mix_b_batched: bad sizes");
+  for (int i = 0; i < count; ++i) {
+    const snws_sn_fwd_item& d = items[i];
+    SNWS_CHECK_ARG(d.ctx && d.gamma && d.mean_weight && d.var_weight, "snws_sn_mix_b_batched: item %d: NULL pointer", i);
+    SNWS_CHECK_ARG(!using_bn || (d.running_mean && d.running_var), "snws_sn_mix_b_batched: item %d: using_bn needs the running buffers", i);
+    SNWS_CHECK_ARG(!(using_bn && training) || d.pack, "snws_sn_mix_b_batched: item %d: training with using_bn needs pack", i);
+    // two calls of one launch that update the same running buffers would race
+    for (int j = 0; j < i; ++j)
+      SNWS_CHECK_ARG(!(using_bn && training) || d.running_mean != items[j].running_mean,
+                     "snws_sn_mix_b_batched: items %d and %d share their running buffers", j, i);
+  }
+  sn_mix_b_batched_kernel<<<dim3((unsigned)cdiv64((int64_t)N * C, 256), 1, count), 256, 0, (hipStream_t)stream>>>(
+      b, N, C, eps, momentum, training, using_movavg, using_bn);
+  SNWS_LAUNCH_CHECK("snws_sn_mix_b_batched");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_apply_batched(const snws_sn_fwd_item* items, int count, int dtype, int N, int64_t HW, int C,
+                                     int relu, void* stream) {
+  SnFwdBatch b;
+  if (int rc = copy_batch(items, count, b.item, "snws_sn_apply_batched")) return rc;
+  SN_COMMON_CHECKS("snws_sn_apply_batched");
+  bool vec = true;
+  for (int i = 0; i < count; ++i) {
+    const snws_sn_fwd_item& d = items[i];
+    SNWS_CHECK_ARG(d.x && d.y && d.ctx && d.beta, "snws_sn_apply_batched: item %d: NULL pointer", i);
+    SNWS_CHECK_ARG(d.ldx >= C && d.ldy >= C, "snws_sn_apply_batched: item %d: pixel stride smaller than C", i);
+    vec = vec && (dtype == SNWS_F32 ? can_vec<float>(C, {d.x, d.y}, {d.ldx, d.ldy})
+                                    : can_vec<bf16_t>(C, {d.x, d.y}, {d.ldx, d.ldy}));
+  }
+  if (!vec) SNWS_UNSUPPORTED("snws_sn_apply_batched: needs 16-byte aligned tensors, strides and channel count");
+  hipStream_t st = (hipStream_t)stream;
+  const int V = dtype == SNWS_F32 ? 4 : 8;
+  const SnMap m = sn_map(C, V);
+  const bool il = sn_interleave();
+  const int T_ = il ? sn_apply_tiles(N, HW, C, 4 * m.PR) : sn_tiles(N, HW, C);
+  const int PT = il ? 0 : (int)cdiv64(HW, T_);
+  const dim3 grid(T_, N, count);
+  if (dtype == SNWS_F32) {
+    if (relu) sn_apply_batched_kernel<float, 4, true><<<grid, SN_THREADS, 0, st>>>(b, N, HW, C, PT, m);
+    else sn_apply_batched_kernel<float, 4, false><<<grid, SN_THREADS, 0, st>>>(b, N, HW, C, PT, m);
+  } else {
+    if (relu) sn_apply_batched_kernel<bf16_t, 8, true><<<grid, SN_THREADS, 0, st>>>(b, N, HW, C, PT, m);
+    else sn_apply_batched_kernel<bf16_t, 8, false><<<grid, SN_THREADS, 0, st>>>(b, N, HW, C, PT, m);
+  }
+  SNWS_LAUNCH_CHECK("snws_sn_apply_batched");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_bwd_a_batched(const snws_sn_bwd_item* items, int count, int N, int C, void* stream) {
+  SnBwdBatch b;
+  if (int rc = copy_batch(items, count, b.item, "snws_sn_bwd_a_batched")) return rc;
+  SNWS_CHECK_ARG(N >= 1 && C >= 1, "snws_sn_bwd_a_batched: bad sizes");
+  for (int i = 0; i < count; ++i) {
+    const snws_sn_bwd_item& d = items[i];
+    SNWS_CHECK_ARG(d.part && d.ctx && d.gamma && d.ctxb && d.packb && d.dgamma && d.dbeta && d.T >= 1,
+                   "snws_sn_bwd_a_batched: item %d: NULL pointer or T < 1", i);
+    for (int j = 0; j < i; ++j)
+      SNWS_CHECK_ARG(d.dgamma != items[j].dgamma && d.dbeta != items[j].dbeta,
+                     "snws_sn_bwd_a_batched: items %d and %d share their gradient buffers", j, i);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  sn_bwd_mix_a1_batched_kernel<<<dim3(cdiv(C, 64), N, count), 512, 0, st>>>(b, N, C);
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_a_batched(1)");
+  sn_bwd_mix_a2_batched_kernel<<<dim3(N + cdiv(C, 256), 1, count), 256, 0, st>>>(b, N, C);
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_a_batched(2)");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_bwd_mix_b_batched(const snws_sn_bwd_item* items, int count, int N, int64_t HW, int C,
+                                         float n_global, int training, int using_bn, void* stream) {
+  SnBwdBatch b;
+  if (int rc = copy_batch(items, count, b.item, "snws_sn_bwd_mix_b_batched")) return rc;
+  SNWS_CHECK_ARG(N >= 1 && C >= 1 && HW >= 1 && n_global >= 1.f && (int64_t)N * C < (1ll << 31),
+                 "snws_sn_bwd_mix_b_batched: bad sizes");
+  for (int i = 0; i < count; ++i) {
+    const snws_sn_bwd_item& d = items[i];
+    SNWS_CHECK_ARG(d.ctx && d.ctxb && d.packb && d.mean_weight && d.var_weight && d.dmean_weight && d.dvar_weight,
+                   "snws_sn_bwd_mix_b_batched: item %d: NULL pointer", i);
+    for (int j = 0; j < i; ++j)
+      SNWS_CHECK_ARG(d.dmean_weight != items[j].dmean_weight && d.dvar_weight != items[j].dvar_weight &&
+                         (!d.dx_sum || d.dx_sum != items[j].dx_sum),
+                     "snws_sn_bwd_mix_b_batched: items %d and %d share their gradient buffers", j, i);
+  }
+  sn_bwd_mix_b_batched_kernel<<<dim3(1, 1, count), 1024, 0, (hipStream_t)stream>>>(b, N, HW, C, n_global, training,
+                                                                                 using_bn);
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_mix_b_batched");
+  return SNWS_OK;
+}
+
+extern "C" int snws_sn_bwd_apply_batched(const snws_sn_bwd_item* items, int count, int dtype, int N, int64_t HW, int C,
+                                         int relu, void* stream) {
+  SnBwdBatch b;
+  if (int rc = copy_batch(items, count, b.item, "snws_sn_bwd_apply_batched")) return rc;
+  SN_COMMON_CHECKS("snws_sn_bwd_apply_batched");
+  bool vec = true;
+  for (int i = 0; i < count; ++i) {
+    const snws_sn_bwd_item& d = items[i];
+    SNWS_CHECK_ARG(d.dy && d.x && d.dx && d.ctx && d.ctxb && d.beta, "snws_sn_bwd_apply_batched: item %d: NULL pointer", i);
+    SNWS_CHECK_ARG(d.lddy >= C && d.ldx >= C && d.lddx >= C, "snws_sn_bwd_apply_batched: item %d: pixel stride smaller than C", i);
+    vec = vec && (dtype == SNWS_F32 ? can_vec<float>(C, {d.dy, d.x, d.dx}, {d.lddy, d.ldx, d.lddx})
+                                    : can_vec<bf16_t>(C, {d.dy, d.x, d.dx}, {d.lddy, d.ldx, d.lddx}));
+  }
+  if (!vec) SNWS_UNSUPPORTED("snws_sn_bwd_apply_batched: needs 16-byte aligned tensors, strides and channel count");
+  hipStream_t st = (hipStream_t)stream;
+  const int V = dtype == SNWS_F32 ? 4 : 8;
+  const SnMap m = sn_map(C, V);
+  const bool il = sn_interleave();
+  const int T_ = il ? sn_apply_tiles(N, HW, C, SN_BWD_ROWS<false> * m.PR) : sn_tiles(N, HW, C);
+  const int PT = il ? 0 : (int)cdiv64(HW, T_);
+  const dim3 grid(T_, N, count);
+  if (dtype == SNWS_F32) {
+    if (relu) sn_bwd_apply_batched_kernel<float, 4, true><<<grid, SN_THREADS, 0, st>>>(b, N, HW, C, PT, m);
+    else sn_bwd_apply_batched_kernel<float, 4, false><<<grid, SN_THREADS, 0, st>>>(b, N, HW, C, PT, m);
+  } else {
+    if (relu) sn_bwd_apply_batched_kernel<bf16_t, 8, true><<<grid, SN_THREADS, 0, st>>>(b, N, HW, C, PT, m);
+    else sn_bwd_apply_batched_kernel<bf16_t, 8, false><<<grid, SN_THREADS, 0, st>>>(b, N, HW, C, PT, m);
+  }
+  SNWS_LAUNCH_CHECK("snws_sn_bwd_apply_batched");
+  return SNWS_OK;
 }
 
 // The apply passes with a per-(image, channel) output multiplier `post` (N x C floats, >= 0) - a feature-dropout mask

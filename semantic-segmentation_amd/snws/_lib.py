@@ -27,6 +27,25 @@ class SnBwdSeg(Structure):
                 ("beta", c_void_p), ("part", c_void_p), ("relu", c_int)]
 
 
+class SnFwdItem(Structure):
+    """snws_sn_fwd_item: one SwitchNorm call of a batched forward launch."""
+    _fields_ = [("part", c_void_p), ("shift", c_void_p), ("ctx", c_void_p), ("pack", c_void_p), ("gamma", c_void_p),
+                ("beta", c_void_p), ("mean_weight", c_void_p), ("var_weight", c_void_p), ("running_mean", c_void_p),
+                ("running_var", c_void_p), ("x", c_void_p), ("y", c_void_p), ("ldx", c_int64), ("ldy", c_int64),
+                ("T", c_int), ("shift_per_image", c_int)]
+
+
+class SnBwdItem(Structure):
+    """snws_sn_bwd_item: one SwitchNorm call of a batched backward launch."""
+    _fields_ = [("part", c_void_p), ("ctx", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("mean_weight", c_void_p), ("var_weight", c_void_p), ("ctxb", c_void_p), ("packb", c_void_p),
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("dmean_weight", c_void_p), ("dvar_weight", c_void_p),
+                ("dx_sum", c_void_p), ("dy", c_void_p), ("x", c_void_p), ("dx", c_void_p), ("lddy", c_int64),
+                ("ldx", c_int64), ("lddx", c_int64), ("T", c_int), ("accumulate_a", c_int), ("accumulate_b", c_int),
+                ("reserved", c_int)]
+
+
+SN_BATCH_MAX = 8
 P = c_void_p
 _SIGNATURES = {
     "snws_version": (c_int, []),
@@ -62,6 +81,12 @@ _SIGNATURES = {
     "snws_sn_mix_a": (c_int, [P, P, c_int, c_int, P]),
     "snws_sn_mix_b": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P]),
     "snws_sn_apply": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, c_int, c_int64, c_int, c_int, P]),
+    "snws_sn_fwd_a_batched": (c_int, [POINTER(SnFwdItem), c_int, c_int, c_int64, c_int, P]),
+    "snws_sn_mix_b_batched": (c_int, [POINTER(SnFwdItem), c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P]),
+    "snws_sn_apply_batched": (c_int, [POINTER(SnFwdItem), c_int, c_int, c_int, c_int64, c_int, c_int, P]),
+    "snws_sn_bwd_a_batched": (c_int, [POINTER(SnBwdItem), c_int, c_int, c_int, P]),
+    "snws_sn_bwd_mix_b_batched": (c_int, [POINTER(SnBwdItem), c_int, c_int, c_int64, c_int, c_float, c_int, c_int, P]),
+    "snws_sn_bwd_apply_batched": (c_int, [POINTER(SnBwdItem), c_int, c_int, c_int, c_int64, c_int, c_int, P]),
     "snws_sn_noalloc_max_floats": (c_int64, []),
     "snws_sn_noalloc_floats": (c_int64, [c_int, c_int64, c_int]),
     "snws_sn_apply_noalloc": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, P, P, P, P, P, P, c_int, c_int64, c_int,

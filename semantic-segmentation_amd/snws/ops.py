@@ -690,12 +690,100 @@ def sync_world(group=None):
 
 
 # Independent SwitchNorm calls whose inputs are all available before any of their outputs is needed - the five
-# branch blocks of a UNet3+ decoder scale (modeling/UNet3p_SNws.py:127-156) - share ONE statistics all-reduce per
-# direction instead of one each: inside `with stat_batch(group):` a synchronised SwitchNorm forward writes its
-# [2C+1] payload into a slot of one buffer and defers its mixing + apply passes; leaving the block all-reduces the
-# used part of the buffer once and runs the deferred passes in order.  Outputs of calls made inside the block must
-# not be read before it ends.
+# branch blocks of a UNet3+ decoder scale (modeling/UNet3p_SNws.py:127-156) - are collected inside
+# `with stat_batch(group):` and run together when the block ends: their per-(image, channel) passes and their
+# normalise passes go out as ONE batched launch per pass (the small passes are latency-bound: five cost what one
+# does), and in data-parallel runs their [2C+1] payloads travel in ONE statistics all-reduce.  Outputs of calls made
+# inside the block must not be read before it ends.  A module used several times inside one block (the shared
+# convu_cat block on up to three sources) keeps its call order: its k-th use runs in the k-th round of launches, so
+# running statistics are updated in the order the reference updates them.  SNWS_SN_BATCH=0: single launches.
 STAT_BATCH = None
+SN_BATCHING = os.environ.get("SNWS_SN_BATCH", "1") != "0"
+
+
+def _rounds(calls, key):
+    """Splits `calls` into rounds such that no round holds two calls of the same key; the k-th call of a key lands in
+    round k, so calls of one key keep their order across rounds."""
+    seen, rounds = {}, []
+    for c in calls:
+        r = seen.get(key(c), 0)
+        seen[key(c)] = r + 1
+        while len(rounds) <= r:
+            rounds.append([])
+        rounds[r].append(c)
+    return rounds
+
+
+def _groups(calls, sig):
+    """The calls of one round grouped by launch signature, at most L.SN_BATCH_MAX per group, order kept."""
+    out = {}
+    for c in calls:
+        g = out.setdefault(sig(c), [[]])
+        if len(g[-1]) == L.SN_BATCH_MAX:
+            g.append([])
+        g[-1].append(c)
+    return [g for gs in out.values() for g in gs]
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _SnCall:
+    """One deferred SwitchNorm forward of a StatBatch."""
+    __slots__ = ("part", "T", "shift", "per_image", "ctx", "pack", "gamma", "beta", "mw", "vw", "rm", "rv", "xs", "ldx",
+                 "y", "ldy", "N", "HW", "C", "dt", "relu", "flags", "esize")
+
+    @property
+    def module_key(self):
+        return _addr(self.rm) if self.rm is not None else _addr(self.gamma)
+
+    @property
+    def sig(self):
+        return (self.N, self.HW, self.C, self.dt, self.relu, self.flags)
+
+    def item(self, it):
+        it.part, it.shift, it.ctx, it.pack = _addr(self.part), _addr(self.shift), _addr(self.ctx), _addr(self.pack)
+        it.gamma, it.beta, it.mean_weight, it.var_weight = _addr(self.gamma), _addr(self.beta), _addr(self.mw), _addr(self.vw)
+        it.running_mean, it.running_var = _addr(self.rm), _addr(self.rv)
+        it.x, it.y, it.ldx, it.ldy = _addr(self.xs), _addr(self.y), self.ldx, self.ldy
+        it.T, it.shift_per_image = self.T, self.per_image
+
+
+def _sn_fwd_a(grp):
+    c0, st = grp[0], _stream()
+    if len(grp) > 1 and SN_BATCHING:
+        items = (L.SnFwdItem * len(grp))()
+        for c, it in zip(grp, items):
+            c.item(it)
+        L.call("snws_sn_fwd_a_batched", items, len(grp), c0.N, c0.HW, c0.C, st)
+        return
+    for c in grp:
+        L.call("snws_sn_finalize", _ptr(c.part), c.T, _ptr(c.shift), c.per_image, c.N, c.HW, c.C, _ptr(c.ctx), st)
+        L.call("snws_sn_mix_a", _ptr(c.ctx), _ptr(c.pack), c.N, c.C, st)
+
+
+def _sn_fwd_b(grp):
+    c0, st = grp[0], _stream()
+    eps, momentum, training, movavg, using_bn = c0.flags
+    work = sum(2.0 * c.esize * c.N * c.HW * c.C for c in grp)
+    if len(grp) > 1 and SN_BATCHING:
+        items = (L.SnFwdItem * len(grp))()
+        for c, it in zip(grp, items):
+            c.item(it)
+        L.call("snws_sn_mix_b_batched", items, len(grp), c0.N, c0.C, eps, momentum, training, movavg, using_bn, st)
+        try:
+            _launch("sn_apply", work, "snws_sn_apply_batched", items, len(grp), c0.dt, c0.N, c0.HW, c0.C, int(c0.relu), st)
+            return
+        except L.SnwsUnsupported:
+            pass
+    else:
+        for c in grp:
+            L.call("snws_sn_mix_b", _ptr(c.ctx), _ptr(c.pack), _ptr(c.gamma), _ptr(c.mw), _ptr(c.vw), _ptr(c.rm), _ptr(c.rv),
+                   c.N, c.C, eps, momentum, training, movavg, using_bn, st)
+    for c in grp:
+        _launch("sn_apply", 2.0 * c.esize * c.N * c.HW * c.C, "snws_sn_apply", _ptr(c.xs), c.ldx, _ptr(c.y), c.ldy, None, 0,
+                c.dt, _ptr(c.ctx), _ptr(c.beta), c.N, c.HW, c.C, int(c.relu), st)
 
 
 class StatBatch:
@@ -713,11 +801,15 @@ class StatBatch:
         return t
 
     def flush(self):
+        calls, self.pending = self.pending, []
+        launches = [g for rnd in _rounds(calls, lambda c: c.module_key) for g in _groups(rnd, lambda c: c.sig)]
+        for g in launches:
+            _sn_fwd_a(g)
         if self.used:
             _allreduce_sum(self.buf[:self.used], self.group)
-        for fn in self.pending:
-            fn()
-        self.buf, self.used, self.pending = None, 0, []
+        for g in launches:      # round by round: a module's later use finds the running statistics of its earlier one
+            _sn_fwd_b(g)
+        self.buf, self.used = None, 0
 
     def __enter__(self):
         global STAT_BATCH
@@ -731,6 +823,8 @@ class StatBatch:
         STAT_BATCH = None
         if exc_type is None:
             self.flush()
+        else:
+            self.pending = []
         return False
 
 
@@ -743,9 +837,9 @@ class _NoBatch:
 
 
 def stat_batch(group=None):
-    """Context manager: a StatBatch when the data-parallel collectives are active, else a no-op (single-GPU runs keep
-    their kernel order)."""
-    return StatBatch(group) if dp_collectives(group) else _NoBatch()
+    """Context manager: a StatBatch when there is something to share - the statistics all-reduce of a data-parallel
+    run, or the batched launches - else a no-op."""
+    return StatBatch(group) if (SN_BATCHING or dp_collectives(group)) else _NoBatch()
 
 
 class SNParams:
@@ -790,14 +884,16 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     else:
         T = stat_part.shape[1]
         per_image = 0
-    L.call("snws_sn_finalize", _ptr(stat_part), T, _ptr(stat_shift), per_image, N, HW, C, _ptr(ctx), st)
     synced = p.sync and p.training and p.using_bn and dp_collectives(p.group)
     world = sync_world(p.group) if synced else 1
-    batch = STAT_BATCH if (apply and synced and STAT_BATCH is not None and STAT_BATCH.group is p.group) else None
-    pack = batch.slot(2 * C + 1, dev) if batch is not None else torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
-    L.call("snws_sn_mix_a", _ptr(ctx), _ptr(pack), N, C, st)
-    if synced and batch is None:
-        _allreduce_sum(pack, p.group)
+    batch = STAT_BATCH if (apply and residual is None and STAT_BATCH is not None and STAT_BATCH.group is p.group) else None
+    pack = batch.slot(2 * C + 1, dev) if (batch is not None and synced) else \
+        torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
+    if batch is None:
+        L.call("snws_sn_finalize", _ptr(stat_part), T, _ptr(stat_shift), per_image, N, HW, C, _ptr(ctx), st)
+        L.call("snws_sn_mix_a", _ptr(ctx), _ptr(pack), N, C, st)
+        if synced:
+            _allreduce_sum(pack, p.group)
     gamma, beta = _f32c(p.gamma).view(-1), _f32c(p.beta).view(-1)
     mw, vw = _f32c(p.mean_weight), _f32c(p.var_weight)
     rm = p.running_mean.view(-1) if p.using_bn else None
@@ -826,8 +922,13 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
         if apply:
             _launch("sn_apply", 2.0 * x.element_size() * N * HW * C, "snws_sn_apply", _ptr(xs), ldx, _ptr(y), ldy, _ptr(rs),
                     ldr, dt, _ptr(ctx), _ptr(beta), N, HW, C, int(relu), st)
-    if batch is not None:
-        batch.pending.append(finish)      # y is filled when the batch is flushed
+    if batch is not None:       # every pass after the statistics runs when the batch is flushed; y is filled then
+        c = _SnCall()
+        c.part, c.T, c.shift, c.per_image, c.ctx, c.pack = stat_part, T, stat_shift, per_image, ctx, pack
+        c.gamma, c.beta, c.mw, c.vw, c.rm, c.rv = gamma, beta, mw, vw, rm, rv
+        c.xs, c.ldx, c.y, c.ldy, c.N, c.HW, c.C, c.dt, c.relu = xs, ldx, y, ldy, N, HW, C, dt, bool(relu)
+        c.flags, c.esize = (eps, momentum, training, movavg, using_bn), x.element_size()
+        batch.pending.append(c)
     else:
         finish()
     n_global = float(N * world) if world > 1 else float(N)
@@ -837,12 +938,13 @@ def sn_forward(x, p, relu, stat_part=None, stat_shift=None, residual=None, out=N
     return y, saved
 
 
-def sn_backward_pass1(dy, s, packb=None, partials=None):
+def sn_backward_pass1(dy, s, packb=None, partials=None, launch=True):
     """First half of the SwitchNorm backward, up to the payload of the backward all-reduce: the two reductions per
     (n, c) (or the partial sums a consumer's dgrad epilogue left), d gamma / d beta, and packb = [sum_n dm, sum_n dv]
     (written into `packb` when given - a slot of a buffer shared by several layers).  Returns the state
     sn_backward_pass2 continues from; the all-reduce of packb happens between the two (sn_backward, or
-    AssembleFn.backward for the layers of a concatenation)."""
+    AssembleFn.backward for the layers of a concatenation).  launch=False: everything but the snws_sn_bwd_mix_a call,
+    which the caller issues for several layers at once (_sn_bwd_a)."""
     N, C, H, W = s["shape"]
     HW = H * W
     lib = L.lib()
@@ -878,10 +980,93 @@ def sn_backward_pass1(dy, s, packb=None, partials=None):
     acc_a = grad_accumulates(dgamma) and grad_accumulates(dbeta)
     if not acc_a and (grad_accumulates(dgamma) or grad_accumulates(dbeta)):
         raise RuntimeError("SwitchNorm weight and bias must be used together")
-    L.call("snws_sn_bwd_mix_a", _ptr(part), T, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(ctxb), _ptr(packb), _ptr(dgamma),
-           _ptr(dbeta), N, C, int(acc_a), st)
+    if launch:
+        L.call("snws_sn_bwd_mix_a", _ptr(part), T, _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(ctxb), _ptr(packb), _ptr(dgamma),
+               _ptr(dbeta), N, C, int(acc_a), st)
     return dict(dys=dys, lddy=lddy, yms=yms, ldym=ldym, ctxb=ctxb, packb=packb, dgamma=dgamma, dbeta=dbeta, dev=dev,
+                part=part, T=T, acc_a=int(acc_a),
                 key=None if dy is None else (dy.data_ptr(), tuple(dy.shape), tuple(dy.stride()), dy._version))
+
+
+def _sn_bwd_item(it, s, p1, q=None):
+    """Fills one snws_sn_bwd_item from a layer's saved forward state, its pass-1 state and (second half) q."""
+    it.part, it.ctx, it.gamma, it.beta = _addr(p1["part"]), _addr(s["ctx"]), _addr(s["gamma"]), _addr(s["beta"])
+    it.mean_weight, it.var_weight = _addr(s["mw"]), _addr(s["vw"])
+    it.ctxb, it.packb, it.dgamma, it.dbeta = _addr(p1["ctxb"]), _addr(p1["packb"]), _addr(p1["dgamma"]), _addr(p1["dbeta"])
+    it.T, it.accumulate_a = p1["T"], p1["acc_a"]
+    if q is not None:
+        it.dmean_weight, it.dvar_weight, it.dx_sum, it.accumulate_b = _addr(q["dmw"]), _addr(q["dvw"]), _addr(q["dxsum"]), q["acc_b"]
+        it.dy, it.lddy, it.x, it.ldx, it.dx, it.lddx = _addr(p1["dys"]), p1["lddy"], _addr(s["xs"]), s["ldx"], _addr(q["dx"]), s["shape"][1]
+
+
+def _sn_bwd_sig(sp):
+    s, p1 = sp
+    return (s["shape"], dtype_code(p1["dys"]), s["relu"], s["n_global"], s["training"], s["using_bn"])
+
+
+def _sn_bwd_a(grp):
+    """snws_sn_bwd_mix_a for the (saved state, pass-1 state) pairs of one launch group."""
+    st = _stream()
+    N, C = grp[0][0]["shape"][:2]
+    if len(grp) > 1:
+        items = (L.SnBwdItem * len(grp))()
+        for (s, p1), it in zip(grp, items):
+            _sn_bwd_item(it, s, p1)
+        L.call("snws_sn_bwd_a_batched", items, len(grp), N, C, st)
+        return
+    for s, p1 in grp:
+        L.call("snws_sn_bwd_mix_a", _ptr(p1["part"]), p1["T"], _ptr(s["ctx"]), _ptr(s["gamma"]), _ptr(p1["ctxb"]),
+               _ptr(p1["packb"]), _ptr(p1["dgamma"]), _ptr(p1["dbeta"]), N, C, p1["acc_a"], st)
+
+
+def _sn_bwd_b(grp):
+    """Second half of the backward (coefficients, d mean_weight / d var_weight, the apply pass) for one launch group;
+    leaves every layer's result in its saved state as "pass2" for sn_backward to hand out."""
+    st = _stream()
+    s0, p0 = grp[0]
+    N, C, H, W = s0["shape"]
+    HW = H * W
+    qs = []
+    for s, p1 in grp:
+        want, key = s.get("dx_sum_req", (False, None))
+        q = _sn_bwd2_buffers(s, p1, want, key)
+        q["dx"] = new_nhwc(N, C, H, W, p1["dys"].dtype, p1["dev"])
+        qs.append(q)
+    dt = dtype_code(p0["dys"])
+    items = (L.SnBwdItem * len(grp))()
+    for (s, p1), q, it in zip(grp, qs, items):
+        _sn_bwd_item(it, s, p1, q)
+    L.call("snws_sn_bwd_mix_b_batched", items, len(grp), N, HW, C, s0["n_global"], int(s0["training"]),
+           int(s0["using_bn"]), st)
+    work = 3.0 * p0["dys"].element_size() * N * HW * C
+    try:
+        _launch("sn_bwd_apply", work * len(grp), "snws_sn_bwd_apply_batched", items, len(grp), dt, N, HW, C,
+                int(s0["relu"]), st)
+    except L.SnwsUnsupported:
+        for (s, p1), q in zip(grp, qs):
+            _launch("sn_bwd_apply", work, "snws_sn_bwd_apply", _ptr(p1["dys"]), p1["lddy"], _ptr(s["xs"]), s["ldx"], None, 0,
+                    _ptr(q["dx"]), C, dt, _ptr(s["ctx"]), _ptr(p1["ctxb"]), _ptr(s["beta"]), N, HW, C, int(s["relu"]), st)
+    for (s, p1), q in zip(grp, qs):
+        s["pass2"] = (p1["key"], _sn_bwd2_result(p1, q))
+
+
+def _sn_bwd2_buffers(s, p1, want_dx_sum, dx_sum_key):
+    """Where the second half of a layer's backward writes its parameter gradients (see grad_out)."""
+    dev = p1["dev"]
+    C = s["shape"][1]
+    K = s["mw"].numel()
+    dmw = grad_out(grad_key(s["mw"]), (K,), dev, acc_ok=True)
+    dvw = grad_out(grad_key(s["vw"]), (K,), dev, acc_ok=True)
+    dxsum = grad_out(dx_sum_key, (C,), dev, acc_ok=True) if want_dx_sum else None
+    if grad_accumulates(dmw) != grad_accumulates(dvw):
+        raise RuntimeError("SwitchNorm mean_weight and var_weight must be used together")
+    acc_b = int(grad_accumulates(dmw)) | (2 if dxsum is not None and grad_accumulates(dxsum) else 0)
+    return dict(dmw=dmw, dvw=dvw, dxsum=dxsum, acc_b=acc_b, want=want_dx_sum)
+
+
+def _sn_bwd2_result(p1, q):
+    res = (q["dx"], grad_fold(p1["dgamma"]), grad_fold(p1["dbeta"]), grad_fold(q["dmw"]), grad_fold(q["dvw"]))
+    return res + (grad_fold(q["dxsum"]),) if q["want"] else res
 
 
 def sn_backward_pass2(s, p1, want_dx_sum=False, dx_sum_key=None, dres_dtype=None, apply_fn=None):
@@ -891,22 +1076,14 @@ def sn_backward_pass2(s, p1, want_dx_sum=False, dx_sum_key=None, dres_dtype=None
     HW = H * W
     st = _stream()
     dys, lddy, yms, ldym, ctxb, packb = p1["dys"], p1["lddy"], p1["yms"], p1["ldym"], p1["ctxb"], p1["packb"]
-    dgamma, dbeta = p1["dgamma"], p1["dbeta"]
     dev = p1["dev"]
-    K = s["mw"].numel()
-    dmw = grad_out(grad_key(s["mw"]), (K,), dev, acc_ok=True)
-    dvw = grad_out(grad_key(s["vw"]), (K,), dev, acc_ok=True)
-    dxsum = grad_out(dx_sum_key, (C,), dev, acc_ok=True) if want_dx_sum else None
-    if grad_accumulates(dmw) != grad_accumulates(dvw):
-        raise RuntimeError("SwitchNorm mean_weight and var_weight must be used together")
-    acc_b = int(grad_accumulates(dmw)) | (2 if dxsum is not None and grad_accumulates(dxsum) else 0)
+    q = _sn_bwd2_buffers(s, p1, want_dx_sum, dx_sum_key)
+    dmw, dvw, dxsum, acc_b = q["dmw"], q["dvw"], q["dxsum"], q["acc_b"]
     L.call("snws_sn_bwd_mix_b", _ptr(s["ctx"]), _ptr(ctxb), _ptr(packb), _ptr(s["mw"]), _ptr(s["vw"]), None, None,
            _ptr(dmw), _ptr(dvw), _ptr(dxsum), N, HW, C, s["n_global"], int(s["training"]), int(s["using_bn"]), acc_b, st)
     if apply_fn is not None:
-        dx = apply_fn(ctxb)
-        if want_dx_sum:
-            return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw), grad_fold(dxsum)
-        return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw)
+        q["dx"] = apply_fn(ctxb)
+        return _sn_bwd2_result(p1, q)
     dt = dtype_code(dys)
     dx = new_nhwc(N, C, H, W, dys.dtype, dev)
     if dres_dtype is not None and dres_dtype == dys.dtype and yms is not None and s["relu"]:
@@ -918,9 +1095,8 @@ def sn_backward_pass2(s, p1, want_dx_sum=False, dx_sum_key=None, dres_dtype=None
         _launch("sn_bwd_apply", 3.0 * dys.element_size() * N * HW * C, "snws_sn_bwd_apply", _ptr(dys), lddy,
                 _ptr(s["xs"]), s["ldx"], _ptr(yms), ldym, _ptr(dx), C, dt, _ptr(s["ctx"]), _ptr(ctxb), _ptr(s["beta"]),
                 N, HW, C, int(s["relu"]), st)
-    if want_dx_sum:
-        return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw), grad_fold(dxsum)
-    return dx, grad_fold(dgamma), grad_fold(dbeta), grad_fold(dmw), grad_fold(dvw)
+    q["dx"] = dx
+    return _sn_bwd2_result(p1, q)
 
 
 def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
@@ -928,6 +1104,15 @@ def sn_backward(dy, s, want_dx_sum=False, dx_sum_key=None, dres_dtype=None):
     per-channel sum of dx, i.e. the gradient of a bias added just before the normalisation.  dres_dtype (residual
     variant only): also produce the gradient of the residual input, [y > 0] * dy, in the apply pass when it has the
     activation dtype; it is left in s["dres"]."""
+    p2 = s.pop("pass2", None)
+    if p2 is not None:
+        # the whole SwitchNorm backward of this layer already ran together with its siblings (AssembleFn.backward)
+        key, res = p2
+        if key != (dy.data_ptr(), tuple(dy.shape), tuple(dy.stride()), dy._version) or \
+                s.get("dx_sum_req", (False, None)) != (bool(want_dx_sum), dx_sum_key if want_dx_sum else None):
+            raise RuntimeError("SwitchNorm backward: the gradient that arrived is not the one the grouped pre-pass "
+                               "worked on (a block output inside a concatenation has a second consumer?)")
+        return res
     p1 = s.pop("pass1", None)
     if p1 is not None:
         # pass 1 and the all-reduce already ran for this layer together with its siblings (AssembleFn.backward)
@@ -1287,6 +1472,8 @@ class ConvSnReluFn(torch.autograd.Function):
         y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift, out=out)
         ctx.prep, ctx.saved, ctx.sn, ctx.has_bias = prep, saved, sn_saved, bias is not None
         ctx.bias_key, ctx.in_segs, ctx.gslot = grad_key(bias), input_segments(x), grad_slot(x)
+        nb = bias is not None and ctx.needs_input_grad[2]
+        sn_saved["dx_sum_req"] = (bool(nb), ctx.bias_key if nb else None)
         ctx.shapes = (gamma.shape, beta.shape)
         ctx.save_for_backward(weight)
         return y
@@ -1742,6 +1929,7 @@ class UpTapSnReluFn(torch.autograd.Function):
         y, sn_saved = sn_forward(conv_out, p, relu, stat_part=stat, stat_shift=shift, out=out)
         ctx.sn, ctx.meta, ctx.has_bias = sn_saved, (N, h, w, k, ksize, c_out, CZ), bias is not None
         ctx.bias_key = grad_key(bias)
+        sn_saved["dx_sum_req"] = (True, ctx.bias_key)
         ctx.shapes = (gamma.shape, beta.shape)
         return y
 
@@ -1786,16 +1974,31 @@ class AssembleFn(torch.autograd.Function):
             off += c
         tags, ctx.tags = ctx.tags, None
         if tags:
-            # data-parallel run: the parts are SwitchNorm block outputs whose ONLY consumer is this concatenation, and
-            # all their incoming gradients exist now - run the first half of each layer's backward here and carry the
-            # five [2C] payloads in ONE all-reduce; each block's own backward then continues from its "pass1" state
-            slots = torch.empty(sum(2 * s["shape"][1] for s in tags), dtype=torch.float32, device=g.device)
-            o = 0
+            # the parts are SwitchNorm block outputs whose ONLY consumer is this concatenation, and all their incoming
+            # gradients exist now: the SwitchNorm backward of all of them runs here - one batched launch per pass and
+            # round (a module used for several parts keeps its order: _rounds), the [2C] payloads of a data-parallel
+            # run in ONE all-reduce - and each block's own backward picks its result up ("pass2"; with SNWS_SN_BATCH=0
+            # only the first half runs here and the block continues from "pass1")
+            synced = tags[0]["synced"]
+            slots = torch.empty(sum(2 * s["shape"][1] for s in tags), dtype=torch.float32, device=g.device) if synced else None
+            o, pairs = 0, []
             for i, s in enumerate(tags):
                 C = s["shape"][1]
-                s["pass1"] = sn_backward_pass1(outs[1 + i], s, packb=slots[o:o + 2 * C])
+                pairs.append((s, sn_backward_pass1(outs[1 + i], s, packb=slots[o:o + 2 * C] if synced else None,
+                                                   launch=not SN_BATCHING)))
                 o += 2 * C
-            _allreduce_sum(slots, tags[0]["group"])
+            if not SN_BATCHING:
+                for s, p1 in pairs:
+                    s["pass1"] = p1
+                _allreduce_sum(slots, tags[0]["group"])
+                return tuple(outs)
+            launches = [grp for rnd in _rounds(pairs, lambda sp: _addr(sp[0]["gamma"])) for grp in _groups(rnd, _sn_bwd_sig)]
+            for grp in launches:
+                _sn_bwd_a(grp)
+            if synced:
+                _allreduce_sum(slots, tags[0]["group"])
+            for grp in launches:
+                _sn_bwd_b(grp)
         return tuple(outs)
 
 
@@ -1811,10 +2014,11 @@ def assemble(buf, parts):
         segs += [(off + c0, c, s) for c0, c, s in tag]
         off += p.shape[1]
     y._snws_seg = segs
-    # one backward statistics all-reduce for all the parts (see AssembleFn.backward) when every part is exactly one
-    # synchronised SwitchNorm layer of the same process group
+    # grouped SwitchNorm backward of all the parts (see AssembleFn.backward) when every part is exactly one SwitchNorm
+    # layer without a residual input, all synchronised over the same process group or none of them
     states = [s for _, _, s in segs]
-    if y.grad_fn is not None and len(states) == len(parts) and all(s["synced"] and s["y"] is None for s in states) and \
+    if y.grad_fn is not None and len(states) == len(parts) and all(s["y"] is None for s in states) and \
+            (SN_BATCHING or states[0]["synced"]) and all(s["synced"] == states[0]["synced"] for s in states) and \
             all(s["group"] is states[0]["group"] for s in states) and \
             all(c0 == sum(q.shape[1] for q in parts[:i]) and c == parts[i].shape[1] for i, (c0, c, _) in enumerate(segs)):
         y.grad_fn.tags = states

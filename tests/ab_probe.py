@@ -58,10 +58,31 @@ def sn_case(tag, shape):
         keep(tag + "_d_" + k, p.grad)
 
 
+def model_case(tag):
+    """One forward / backward of a small UNet3p_SNws: the decoder's five branch blocks per scale (one module on up to
+    three of them), the shared-gradient tap maps, the fused head."""
+    from modeling.UNet3p_SNws import UNet3p_SNws
+    torch.manual_seed(5)
+    model = UNet3p_SNws(14, 16, 10, 1, 1).to(DEV).train()
+    model.compute_dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    img = (torch.rand(2, 14, 64, 64, generator=g) * 255.0).to(DEV)
+    lab = torch.randint(0, 10, (2, 64, 64), generator=g).to(DEV)
+    logits = model(img)
+    loss = torch.nn.functional.cross_entropy(logits.float(), lab)
+    loss.backward()
+    keep(tag + "_logits", logits)
+    for k, p in model.named_parameters():
+        keep(tag + "_d_" + k, p.grad)
+    for k, b in model.named_buffers():
+        keep(tag + "_buf_" + k, b)
+
+
 block_case("b64", 64, 64, 2, 40, 72)          # interior and border tiles of every 3x3 kernel
 block_case("b128", 128, 64, 1, 17, 50)        # ragged sizes, two in-channel tiles
 block_case("b320", 320, 320, 1, 24, 40)       # five channel tiles on both sides
 sn_case("s24", (2, 24, 33, 17))               # stand-alone statistics / backward reduction, odd sizes
 sn_case("s320", (1, 320, 40, 48))             # 240 active threads per workgroup
+model_case("m16")
 torch.cuda.synchronize()
 np.savez(sys.argv[1], **out)

