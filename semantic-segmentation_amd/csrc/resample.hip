@@ -137,6 +137,56 @@ __global__ __launch_bounds__(256) void resample_bwd_window_kernel(const T* __res
   }
 }
 
+// 2x2 max-pool backward (every pooling step of the encoder and of the pooled skip pyramid): as the window kernel, but
+// the four source vectors, the incoming gradient and - when accumulating - the four destination vectors are all
+// requested before the first comparison, instead of one dependent load per loop iteration.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ ddst, int64_t ldd,
+                                                        const T* __restrict__ src, int64_t lds_, T* __restrict__ dsrc,
+                                                        int64_t ldds, int N, int H, int W, int OH, int OW, int C,
+                                                        int accumulate) {
+  const int CG = C / V;
+  const int64_t total = (int64_t)N * OH * OW * CG;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    int64_t p = idx / CG;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int n = (int)(p / OH);
+    const int y0 = 2 * oy, x0 = 2 * ox;
+    const bool ok[4] = {true, x0 + 1 < W, y0 + 1 < H, x0 + 1 < W && y0 + 1 < H};      // ceil mode: ragged last windows
+    const int64_t base = (int64_t)y0 * W + x0;
+    const int64_t off[4] = {base, base + (ok[1] ? 1 : 0), base + (ok[2] ? W : 0), base + (ok[3] ? W + 1 : 0)};
+    const T* sn = src + (int64_t)n * H * W * lds_ + (int64_t)cg * V;
+    T* dn = dsrc + (int64_t)n * H * W * ldds + (int64_t)cg * V;
+    float g[V], a[4][V], d[4][V];
+    Vec<T, V>::load(ddst + (((int64_t)n * OH + oy) * OW + ox) * ldd + (int64_t)cg * V, g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) VecNT<T, V>::load(sn + off[q] * lds_, a[q]);
+    if (accumulate) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Vec<T, V>::load(dn + off[q] * ldds, d[q]);
+    }
+    int arg[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float best = a[0][v];
+      arg[v] = 0;
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (ok[q] && (a[q][v] > best || (a[q][v] != a[q][v] && best == best))) { best = a[q][v]; arg[v] = q; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!ok[q]) continue;
+      float r[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) r[v] = (accumulate ? d[q][v] : 0.f) + (arg[v] == q ? g[v] : 0.f);
+      VecNT<T, V>::store(dn + off[q] * ldds, r);
+    }
+  }
+}
+
 // bilinear backward: one thread per SOURCE pixel and channel group
 template <typename T, int V>
 __global__ __launch_bounds__(256) void resample_bwd_bilinear_kernel(const T* __restrict__ ddst, int64_t ldd,
@@ -226,7 +276,10 @@ int run_bwd(const void* ddst, int64_t ldd, const void* src, int64_t lds_, void* 
     resample_bwd_bilinear_kernel<T, V><<<grid_for(total), 256, 0, st>>>((const T*)ddst, ldd, (T*)dsrc, ldds, N, H, W, OH, OW, C, k, accumulate);
   } else {
     const int64_t total = (int64_t)N * OH * OW * (C / V);
-    resample_bwd_window_kernel<T, V><<<grid_for(total), 256, 0, st>>>((const T*)ddst, ldd, (const T*)src, lds_, (T*)dsrc, ldds, N, H, W, OH, OW, C, mode, k, accumulate);
+    if (mode == MODE_MAXPOOL && k == 2)
+      pool2_bwd_kernel<T, V><<<grid_for(total), 256, 0, st>>>((const T*)ddst, ldd, (const T*)src, lds_, (T*)dsrc, ldds, N, H, W, OH, OW, C, accumulate);
+    else
+      resample_bwd_window_kernel<T, V><<<grid_for(total), 256, 0, st>>>((const T*)ddst, ldd, (const T*)src, lds_, (T*)dsrc, ldds, N, H, W, OH, OW, C, mode, k, accumulate);
   }
   SNWS_LAUNCH_CHECK("snws_resample_bwd");
   return SNWS_OK;

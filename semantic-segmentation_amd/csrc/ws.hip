@@ -58,11 +58,16 @@ __global__ __launch_bounds__(WS_THREADS) void ws_fwd_kernel(const float* __restr
   }
 }
 
+// The gradient arrives in the weight-gradient kernels' layout (out ch, tap, in ch) while w and dw are (out ch, in ch,
+// tap): the channel's gradient row is read the way it lies in memory - consecutive lanes, consecutive addresses - into
+// LDS at its transposed position (stride `taps` words: conflict-free for the odd tap counts 1 and 9) and picked up from
+// there; a gather straight from global touched nine rows per wave instruction and used 28 bytes of every line.
 template <int PT>
 __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restrict__ w, const float* __restrict__ g,
                                                             int64_t ldg, float* __restrict__ dw, int O, int I, int kh,
                                                             int kw, int accumulate) {
   __shared__ double scratch[16];
+  extern __shared__ float gt[];     // n floats: the gradient row in (in ch, tap) order
   const int o = blockIdx.x;
   const int taps = kh * kw, n = I * taps;
   const float* wo = w + (int64_t)o * n;
@@ -74,15 +79,30 @@ __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restr
     c[k] = i < n ? wo[i] : 0.f;
     s += c[k];
   }
-  const float mu = (float)(block_sum(s, scratch) / n);
+#pragma unroll
+  for (int k = 0; k < PT; ++k) {
+    const int j = threadIdx.x + k * WS_THREADS;     // (tap, in ch) order
+    if (j < n) {
+      const int tap = j / I, ci = j - tap * I;
+      gg[k] = g[((int64_t)o * taps + tap) * ldg + ci];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PT; ++k) {
+    const int j = threadIdx.x + k * WS_THREADS;
+    if (j < n) {
+      const int tap = j / I, ci = j - tap * I;
+      gt[ci * taps + tap] = gg[k];
+    }
+  }
+  const float mu = (float)(block_sum(s, scratch) / n);      // (its barriers also publish gt)
   double ss = 0, gc = 0;
 #pragma unroll
   for (int k = 0; k < PT; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
     if (i < n) {
-      const int ci = i / taps, tap = i % taps;
       c[k] -= mu;
-      gg[k] = g[((int64_t)o * taps + tap) * ldg + ci];
+      gg[k] = gt[i];
     } else {
       c[k] = 0.f;
       gg[k] = 0.f;
@@ -94,11 +114,12 @@ __global__ __launch_bounds__(WS_THREADS) void ws_bwd_kernel(const float* __restr
   gc = block_sum(gc, scratch);
   const double d = sdev + 1e-5;
   const double k2 = gc / (d * d * (n - 1) * sdev);
+  const double inv_d = 1.0 / d;     // one f64 division per channel instead of one per element
   double ts = 0;
 #pragma unroll
   for (int k = 0; k < PT; ++k) {
     const int i = threadIdx.x + k * WS_THREADS;
-    const double t = i < n ? (double)gg[k] / d - k2 * c[k] : 0.0;
+    const double t = i < n ? (double)gg[k] * inv_d - k2 * c[k] : 0.0;
     gg[k] = (float)t;
     ts += t;
   }
@@ -152,8 +173,24 @@ extern "C" int snws_ws_bwd(const float* w, const float* g_ohwi, int64_t ldg, flo
   const int64_t n = (int64_t)I * kh * kw;
   SNWS_CHECK_ARG(n >= 2, "snws_ws_bwd: fan-in %lld < 2", (long long)n);
   if (n > (int64_t)WS_THREADS * WS_MAX_PER_THREAD) SNWS_UNSUPPORTED("snws_ws_bwd: fan-in %lld too large", (long long)n);
-#define WS_BWD(PT) ws_bwd_kernel<PT><<<O, WS_THREADS, 0, (hipStream_t)stream>>>(w, g_ohwi, ldg, dw, O, I, kh, kw, accumulate)
-  if (n <= 4 * WS_THREADS) WS_BWD(4); else if (n <= 16 * WS_THREADS) WS_BWD(16); else WS_BWD(64);
+#define WS_BWD(PT) ws_bwd_kernel<PT><<<O, WS_THREADS, (size_t)n * sizeof(float), (hipStream_t)stream>>>(w, g_ohwi, ldg, dw, O, I, kh, kw, accumulate)
+  if (n <= 4 * WS_THREADS) WS_BWD(4);
+  else if (n <= 16 * WS_THREADS) WS_BWD(16);
+  else {
+    // up to 64 KB for the staged gradient row beside the static reduction scratch: above the default limit
+    static PerDeviceOnce once;
+    std::atomic<bool>* const attr_set = once.flag();
+    if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_bwd_kernel<64>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, WS_THREADS * WS_MAX_PER_THREAD * (int)sizeof(float));
+      if (e != hipSuccess) {
+        snws_set_error("snws_ws_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return SNWS_ERR_HIP;
+      }
+      if (attr_set) attr_set->store(true, std::memory_order_release);
+    }
+    WS_BWD(64);
+  }
 #undef WS_BWD
   SNWS_LAUNCH_CHECK("snws_ws_bwd");
   return SNWS_OK;

@@ -186,6 +186,29 @@ def test_ws_fwd_bwd_golden():
         assert relerr(dw, 2 * want) < 1e-4
 
 
+@pytest.mark.parametrize("shape,ldg", [((64, 320, 3, 3), 320), ((32, 1024, 3, 3), 1024), ((8, 1820, 3, 3), 1824),
+                                       ((16, 576, 1, 1), 576), ((5, 7, 3, 3), 16)])
+def test_ws_bwd_wide_fan_in_vs_oracle(shape, ldg):
+    """snws_ws_bwd on the fan-in classes of the benchmark model (16 and 64 elements per thread; 1820 input channels is
+    the widest filter the kernel takes: its staged gradient row fills 64 KB of LDS) and with a padded channel stride of
+    the incoming gradient, against the closed-form float64 backward of the oracle."""
+    import ctypes
+    from snws import _lib as L
+    torch.manual_seed(4)
+    w = torch.randn(shape) * 0.05
+    gr = torch.randn(shape)
+    want = O.ws_standardize_bwd(w.double(), gr.double())
+    Oc, I, kh, kw = shape
+    g_ohwi = torch.zeros(Oc, kh, kw, ldg)
+    g_ohwi[..., :I] = gr.permute(0, 2, 3, 1)
+    wd, gd = w.to(DEV), g_ohwi.to(DEV)
+    dw = torch.empty_like(wd)
+    L.call("snws_ws_bwd", ctypes.c_void_p(wd.data_ptr()), ctypes.c_void_p(gd.data_ptr()), ldg,
+           ctypes.c_void_p(dw.data_ptr()), Oc, I, kh, kw, 0, None)
+    torch.cuda.synchronize()
+    assert relerr(dw, want) < 1e-5
+
+
 # ================================================================== direct convolution (exact f32 tier)
 @pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("ci", range(4))
