@@ -2139,7 +2139,7 @@ struct WgradPlan {
   bool wide;
 };
 
-WgradPlan wgrad_plan(const snws_conv_desc* d, bool det) {
+WgradPlan wgrad_plan(const snws_conv_desc* d, bool det, bool with_bias) {
   WgradPlan p;
   const bool c16 = d->C_in == 16, c64 = !c16;
   const int taps = d->kh * d->kw;
@@ -2203,9 +2203,16 @@ WgradPlan wgrad_plan(const snws_conv_desc* d, bool det) {
   // (320->320: @512^2 981 TFLOP/s with 512 workgroups, 1045 with 2048, 1158 with 8192; @256^2 1077 / 1116 / 1078
   // with 2048 / 3072 / 8192).  The partial-tile flush (det) keeps the same cut: its stores are ~5x cheaper than the
   // atomics, but every split is read back once by the reducer.
+  // The ping-pong 3x3 kernel (no bias sums, >= wgrad9_pp_min_pairs() channel-tile pairs) shares the x tile inside its
+  // workgroup and keeps the sibling pairs of a pixel slice in step by construction, so it wants the other extreme: ONE
+  // resident round of 256 workgroups x 2 items, each a long sweep - 320->320 @512^2 5.43 -> 5.10 ms, @256^2 1.46 -> 1.27
+  // ms against the ~32-tile items; 1024 items equal, 768 (one and a half rounds) 25 % slower, 256 (half the chip idle
+  // in a workgroup's second half) 50 % slower - and its partial tiles shrink from 1.2 GB to 74 MB on that layer.
   (void)det;
+  const bool pingpong = p.kind == 5 && wgrad9_pp() && !with_bias && p.npairs >= wgrad9_pp_min_pairs();
   const int64_t sweep = (int64_t)p.ntiles * p.npairs;
   const int target_blocks = forced_blocks > 0 ? forced_blocks
+                            : pingpong ? 512
                             : sweep >= 32ll * 2048 ? (int)(sweep / 32 < 8192 ? sweep / 32 : 8192) : 512;
   int splits = target_blocks / p.npairs;   // never more than target_blocks workgroups: two extra ones cost a whole extra round
   if (splits < 1) splits = 1;
@@ -2225,7 +2232,7 @@ int run_wgrad(const char* fn, const snws_conv_desc* d, const void* x, const void
   SNWS_CHECK_ARG(x && dy && dw_ohwi, "%s: NULL pointer", fn);
   SNWS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "%s: pointers must be 16-byte aligned", fn);
   const bool det = ws != nullptr;
-  const WgradPlan p = wgrad_plan(d, det);
+  const WgradPlan p = wgrad_plan(d, det, dbias != nullptr);
   SNWS_CHECK_ARG(p.ntiles > 0, "%s: too many pixels", fn);
   float* part = nullptr;
   float* pbias = nullptr;
@@ -2287,9 +2294,11 @@ extern "C" int snws_conv_mfma_wgrad(const snws_conv_desc* d, const void* x, cons
 
 extern "C" int64_t snws_conv_mfma_wgrad_workspace_bytes(const snws_conv_desc* d) {
   if (!d || check_mfma_desc(d, "snws_conv_mfma_wgrad_workspace_bytes")) return -1;
-  const WgradPlan p = wgrad_plan(d, true);
-  if (p.ntiles <= 0) return -1;
-  return wgrad_ws_floats(p) * 4;
+  // the cut of the work depends on whether the bias gradient is asked for: enough for either call
+  const WgradPlan p = wgrad_plan(d, true, false), pb = wgrad_plan(d, true, true);
+  if (p.ntiles <= 0 || pb.ntiles <= 0) return -1;
+  const int64_t f = wgrad_ws_floats(p), fb = wgrad_ws_floats(pb);
+  return (f > fb ? f : fb) * 4;
 }
 
 extern "C" int snws_conv_mfma_wgrad_det(const snws_conv_desc* d, const void* x, const void* dy, float* dw_ohwi,

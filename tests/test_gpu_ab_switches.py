@@ -32,15 +32,26 @@ def _rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(float(np.linalg.norm(b.astype(np.float64))), 1e-30))
 
 
-@pytest.mark.parametrize("switch", ["SNWS_WGRAD9_PP", "SNWS_PRIO"])
-def test_matrix_kernel_variants_are_bit_identical(default_run, tmp_path, switch):
-    # SNWS_WGRAD9_PP=0: every 3x3 weight gradient on conv_wgrad9q_kernel (two independent workgroups per CU) instead of
-    # the ping-pong kernel (one 8-wave workgroup whose halves alternate): same wave split, same order of every
-    # accumulation, same partial-tile layout - not a bit may change.  SNWS_PRIO=0: no wave priorities in the 3x3 kernels.
-    other = _run(tmp_path, switch, {switch: "0"})
+def test_wave_priority_changes_no_bit(default_run, tmp_path):
+    # SNWS_PRIO=0: no wave priorities in the 3x3 matrix kernels - scheduling only
+    other = _run(tmp_path, "prio", {"SNWS_PRIO": "0"})
+    for k in default_run.files:
+        assert np.array_equal(other[k], default_run[k]), (k, _rel(other[k], default_run[k]))
+
+
+def test_wgrad_launch_forms_agree(default_run, tmp_path):
+    # SNWS_WGRAD9_PP=0: every 3x3 weight gradient on conv_wgrad9q_kernel (two independent workgroups per CU, ~32 pixel
+    # tiles per work item) instead of the ping-pong kernel (one 8-wave workgroup per CU, one resident round of long
+    # work items).  Same wave body and order inside a work item; the pixel tiles are cut into different partial sums,
+    # so filter gradients may move by float32 rounding - and nothing else may move at all.
+    other = _run(tmp_path, "pp", {"SNWS_WGRAD9_PP": "0"})
+    # (at the probe's sizes both forms cut the pixel tiles alike and every bit agrees; the cuts differ from about 64 K
+    # pixel-tile x channel-pair products upwards, where tests/test_gpu_fullsize.py checks both against exact checksums)
     for k in default_run.files:
         a, b = other[k], default_run[k]
-        assert np.array_equal(a, b), (switch, k, _rel(a, b))
+        if np.array_equal(a, b):
+            continue
+        assert a.ndim == 4 and "_d_" in k and _rel(a, b) < 1e-5, (k, _rel(a, b))
 
 
 def test_streaming_walk_variants_agree(default_run, tmp_path):
