@@ -2060,7 +2060,7 @@ bool wgrad9_pp() {
 }
 
 int wgrad9_pp_min_pairs() {
-  static const int n = getenv("SNWS_WGRAD9_PP_MIN_PAIRS") ? atoi(getenv("SNWS_WGRAD9_PP_MIN_PAIRS")) : 4;
+  static const int n = getenv("SNWS_WGRAD9_PP_MIN_PAIRS") ? atoi(getenv("SNWS_WGRAD9_PP_MIN_PAIRS")) : 2;
   return n;
 }
 
