@@ -468,6 +468,12 @@ int snws_upconv_fwd(const void* Z, int64_t ldz, void* y, int64_t ldy, const floa
                     int w, int C_out, int k, int ksize, void* stream);
 int snws_upconv_bwd(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dtype, int N, int h, int w, int C_out,
                     int k, int ksize, void* stream);
+/* dZ += the same gradient: for a tap map Z consumed at several decoder scales (modeling/UNet3p_SNws.py:131-155 up-samples
+ * hd5 / hd4 / hd3 for every finer scale), whose later consumers add their share into the first one's tensor instead of
+ * leaving the sum to autograd.  Only the k = 2 matrix-core kernel adds in place (bf16, 3x3, C_out a multiple of 64):
+ * SNWS_ERR_UNSUPPORTED otherwise - then call snws_upconv_bwd into a temporary and snws_add_inplace. */
+int snws_upconv_bwd_acc(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dtype, int N, int h, int w, int C_out,
+                        int k, int ksize, void* stream);
 /* snws_upconv_fwd that also emits what the SwitchNorm after the block (modeling/UNet3p_SNws.py:29-33) needs:
  * stat_part [N][T][C_out][2], T = snws_upconv_stat_tiles(h*k, w*k): per 8x32 output strip the sum and the sum of
  * squares of (y - bias[c]) over the strip's valid pixels, y as stored (rounded) - the layout snws_sn_finalize takes

@@ -1304,7 +1304,8 @@ struct UpB2 {
 
 __global__ __launch_bounds__(256, 2) void upconv_bwd_mfma2_kernel(const bf16_t* __restrict__ dy, int64_t lddy,
                                                                  bf16_t* __restrict__ dZ, int64_t lddz, int h, int w,
-                                                                 int Co, int tilesX, int tilesPerWg) {
+                                                                 int Co, int tilesX, int tilesPerWg, int accumulate) {
+  // accumulate != 0: dZ += result (a tap map consumed at several decoder scales: the later consumers add in place)
   using G = UpB2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1395,9 +1396,12 @@ __global__ __launch_bounds__(256, 2) void upconv_bwd_mfma2_kernel(const bf16_t* 
       for (int it = 0; it < 2; ++it) {
         const int q = it * 64 + lane, p16 = q >> 3, c8 = q & 7;
         const int sy = sy0 + (p16 >> 2), sx = sxb + (p16 & 3);
-        if (sy < h && sx < w)
-          *reinterpret_cast<uint4*>(dZ + (((int64_t)n * h + sy) * w + sx) * lddz + (int64_t)tap * Co + cchunk * 64 + c8 * 8) =
-              *reinterpret_cast<const uint4*>(scr + p16 * G::SCR_RS + c8 * 16);
+        if (sy < h && sx < w) {
+          uint4* dst = reinterpret_cast<uint4*>(dZ + (((int64_t)n * h + sy) * w + sx) * lddz + (int64_t)tap * Co + cchunk * 64 + c8 * 8);
+          uint4 v = *reinterpret_cast<const uint4*>(scr + p16 * G::SCR_RS + c8 * 16);
+          if (accumulate) v = add_bf16x8(v, *dst);      // kernel-uniform
+          *dst = v;
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1523,7 +1527,8 @@ int launch_bwd_mfma4(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int N
   return SNWS_OK;
 }
 
-int launch_bwd_mfma2(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int N, int h, int w, int Co, hipStream_t st) {
+int launch_bwd_mfma2(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int N, int h, int w, int Co, hipStream_t st,
+                     int accumulate = 0) {
   using G = UpB2;
   static PerDeviceOnce once;
   std::atomic<bool>* const attr_set = once.flag();
@@ -1544,7 +1549,8 @@ int launch_bwd_mfma2(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int N
   const int tilesPerWg = cdiv(tilesX, xsplits);
   xsplits = cdiv(tilesX, tilesPerWg);
   dim3 grid((unsigned)((Co / 64) * xsplits), (unsigned)tilesY, (unsigned)N);
-  upconv_bwd_mfma2_kernel<<<grid, 256, G::LDS_BYTES, st>>>((const bf16_t*)dy, lddy, (bf16_t*)dZ, lddz, h, w, Co, tilesX, tilesPerWg);
+  upconv_bwd_mfma2_kernel<<<grid, 256, G::LDS_BYTES, st>>>((const bf16_t*)dy, lddy, (bf16_t*)dZ, lddz, h, w, Co, tilesX, tilesPerWg,
+                                                           accumulate);
   return SNWS_OK;
 }
 
@@ -1647,6 +1653,18 @@ extern "C" int snws_upconv_fwd_stats(const void* Z, int64_t ldz, void* y, int64_
   if (int rc = upconv_mfma_on(k) ? launch_fwd_mfma(Z, ldz, y, ldy, bias, stat_part, N, h, w, C_out, k, (hipStream_t)stream)
                                 : launch_fwd_lds(Z, ldz, y, ldy, bias, stat_part, N, h, w, C_out, k, (hipStream_t)stream)) return rc;
   SNWS_LAUNCH_CHECK("snws_upconv_fwd_stats");
+  return SNWS_OK;
+}
+
+extern "C" int snws_upconv_bwd_acc(const void* dy, int64_t lddy, void* dZ, int64_t lddz, int dtype, int N, int h, int w,
+                                   int C_out, int k, int ksize, void* stream) {
+  if (int rc = check("snws_upconv_bwd_acc", dtype, N, h, w, C_out, k, ksize)) return rc;
+  SNWS_CHECK_ARG(dy && dZ && lddz >= (int64_t)ksize * ksize * C_out && lddy >= C_out, "snws_upconv_bwd_acc: NULL pointer or bad stride");
+  if (!(dtype == SNWS_BF16 && ksize == 3 && k == 2 && C_out % 64 == 0 && lddz % 8 == 0 && lddy % 8 == 0 && al16(dZ) && al16(dy) &&
+        upconv_bwd_mfma_on() && N <= 65535 && cdiv(h, 4) <= 65535))
+    SNWS_UNSUPPORTED("snws_upconv_bwd_acc: only the k = 2 matrix-core kernel adds in place (bf16, 3x3, C_out a multiple of 64)");
+  if (int rc = launch_bwd_mfma2(dy, lddy, dZ, lddz, N, h, w, C_out, (hipStream_t)stream, 1)) return rc;
+  SNWS_LAUNCH_CHECK("snws_upconv_bwd_acc");
   return SNWS_OK;
 }
 

@@ -129,6 +129,7 @@ _SIGNATURES = {
     "snws_upconv_bwd_mode": (c_int, [c_int]),
     "snws_upconv_fwd_stats": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "snws_upconv_bwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "snws_upconv_bwd_acc": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_resample_fwd": (c_int, [P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "snws_resample_bwd": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, P]),

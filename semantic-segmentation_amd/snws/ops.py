@@ -1938,12 +1938,28 @@ class UpTapSnReluFn(torch.autograd.Function):
         N, h, w, k, ksize, c_out, CZ = ctx.meta
         dconv, dg, dbeta, dmw, dvw, dxsum = sn_backward(dy, ctx.sn, want_dx_sum=True, dx_sum_key=ctx.bias_key)
         ctx.sn = None
-        dz = new_nhwc(N, CZ, h, w, dconv.dtype, dconv.device)
         work = float(dconv.element_size()) * N * c_out * (h * w * ksize * ksize + h * k * w * k)
-        _launch("upconv_bwd", work, "snws_upconv_bwd", _ptr(dconv), c_out, _ptr(dz), CZ, dtype_code(dconv), N, h, w,
-                c_out, k, ksize, _stream())
+        slot, ctx.gslot = ctx.gslot, None
+        dz, added = None, False
+        parked = None if slot is None else slot.buf
+        if parked is not None and parked.dtype == dconv.dtype and tuple(parked.shape) == (N, CZ, h, w):
+            # a later consumer of a shared tap map: the kernel adds its share into the parked gradient where it can
+            ps, ldp = as_nhwc(parked)
+            if ps.data_ptr() == parked.data_ptr():
+                try:
+                    _launch("upconv_bwd", work, "snws_upconv_bwd_acc", _ptr(dconv), c_out, _ptr(ps), ldp, dtype_code(dconv),
+                            N, h, w, c_out, k, ksize, _stream())
+                    global GRAD_SHARE_HITS
+                    GRAD_SHARE_HITS += 1
+                    added = True
+                except L.SnwsUnsupported:
+                    pass
+        if not added:
+            dz = new_nhwc(N, CZ, h, w, dconv.dtype, dconv.device)
+            _launch("upconv_bwd", work, "snws_upconv_bwd", _ptr(dconv), c_out, _ptr(dz), CZ, dtype_code(dconv), N, h, w,
+                    c_out, k, ksize, _stream())
+            dz = deliver_grad(slot, dz)
         db = dxsum if ctx.has_bias else None
-        dz, ctx.gslot = deliver_grad(ctx.gslot, dz), None
         return dz, db, _view(dg, ctx.shapes[0]), _view(dbeta, ctx.shapes[1]), dmw, dvw, None, None, None, None, None, None
 
 

@@ -2240,3 +2240,33 @@ def test_switchnorm_batched_launch_rejects_shared_buffers():
     with pytest.raises(ValueError, match="count"):
         L.call("snws_sn_mix_b_batched", items, 9, N, C, 1e-5, 0.997, 0, 1, 1, st)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_upconv_bwd_accumulating_form_equals_temporary_plus_add():
+    """snws_upconv_bwd_acc (a later consumer of a shared tap map adds its share in the kernel's store epilogue) against
+    snws_upconv_bwd into a temporary followed by snws_add_inplace: the same float32 sum of the same two bf16 values,
+    rounded once - bit for bit; factors the in-place form does not take are refused, not silently overwritten."""
+    import ctypes
+    from snws import _lib as L
+    torch.manual_seed(31)
+    N, h, w, Co, k = 2, 13, 22, 64, 2
+    dy = torch.randn(N, h * k, w * k, Co, device=DEV).to(torch.bfloat16)
+    base = torch.randn(N, h, w, 9 * Co, device=DEV).to(torch.bfloat16)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    tmp = torch.empty_like(base)
+    L.call("snws_upconv_bwd", P(dy), Co, P(tmp), 9 * Co, L.SNWS_BF16, N, h, w, Co, k, 3, st)
+    want = base.clone()
+    L.call("snws_add_inplace", P(want), 9 * Co, P(tmp), 9 * Co, L.SNWS_BF16, N * h * w, 9 * Co, st)
+    got = base.clone()
+    L.call("snws_upconv_bwd_acc", P(dy), Co, P(got), 9 * Co, L.SNWS_BF16, N, h, w, Co, k, 3, st)
+    torch.cuda.synchronize()
+    assert float(tmp.float().abs().max()) > 0
+    assert torch.equal(got, want)
+    dy4 = torch.randn(N, h * 4, w * 4, Co, device=DEV).to(torch.bfloat16)
+    keep = got.clone()
+    with pytest.raises(L.SnwsUnsupported):
+        L.call("snws_upconv_bwd_acc", P(dy4), Co, P(got), 9 * Co, L.SNWS_BF16, N, h, w, Co, 4, 3, st)
+    torch.cuda.synchronize()
+    assert torch.equal(got, keep)
