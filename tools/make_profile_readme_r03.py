@@ -66,8 +66,8 @@ out = ["## Round 3", "",
        % (bo["value"], bo["ms_per_step"], "no rocBLAS / hipBLASLt (`Cijk_*`) kernel" if not vendor else "VENDOR GEMM KERNELS PRESENT",
           100.0 * oours / otot),
        "* `r03_pmc_sq_conv_wgrad.txt` - SQ / GRBM counters of the 3x3 forward and weight-gradient kernels on the 320->320 layer "
-       "(`tools/run_pmc.sh conv | wgrad`): the ping-pong weight-gradient kernel fetches 6.9 GB for 5.4 GB of operands (round 2: 18.1 GB), "
-       "matrix pipe busy 76 % of the active cycles at an effective clock of 1.75 GHz; the forward kernel 76 % at 1.77 GHz.",
+       "(`tools/run_pmc.sh conv | wgrad`): the ping-pong weight-gradient kernel fetches 6.8 GB and writes 0.07 GB for 5.4 GB of operands (round 2: 18.1 + 1.2 GB), "
+       "matrix pipe busy 78 % of the active cycles at an effective clock of 1.78 GHz; the forward kernel 76 % at 1.79 GHz.",
        "* `r03_rccl_one_rank_timeline.txt`, `r03_rccl_one_rank_kernel_stats.csv` - the bench under `SNWS_DP_SELFTEST=1` (every collective of "
        "the data-parallel path issued to a one-rank RCCL communicator; `tools/rccl_timeline.sh`): RCCL launches no device kernel for a one-rank "
        "all-reduce, so the 36 statistic all-reduces per step show as 10-12 us hand-over windows of the compute stream between "
