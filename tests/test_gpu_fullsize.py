@@ -444,7 +444,7 @@ def test_predict_disk_full_fy4a_disk_matches_tile_by_tile():
     assert np.array_equal(ev._matrix(), O.confusion_matrix(gt.numpy(), got[None].cpu().numpy(), 10).astype(np.float64))
 
 
-# ================================================================== round-2 kernels at the benchmark's sizes
+# ================================================================== fused head, wide 1x1 and OCR kernels at the benchmark's sizes
 @pytest.mark.parametrize("N_out,K", [(512, 1024), (576, 320)])
 def test_gemm1x1_full_size_exact_checksums(N_out, K):
     """snws_gemm1x1 over all 16 x 512 x 512 pixels (OCR head's 1024 -> 512 layer; the 320 -> 576 tap convolution at
