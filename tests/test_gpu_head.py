@@ -199,9 +199,9 @@ def test_head_entry_points_reject_unsupported_shapes():
 # ================================================================== shared gradients of multi-consumer tensors
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
 def test_shared_gradient_slots_match_autograd_accumulation(dtype, tol):
-    """A tensor consumed by two fused conv blocks, a max-pool and a tap convolution + two up-sampled consumers of its
-    tap map: with ops.share_grad the consumers add their gradients in place (dgrad epilogue, pooling backward,
-    snws_add_inplace); the input gradient and every parameter gradient must equal what autograd's own accumulation
+    """A tensor consumed by two fused conv blocks, a max-pool and a tap convolution + three up-sampled consumers of its
+    tap map: with ops.share_grad the consumers add their gradients in place (dgrad epilogue, pooling backward, the
+    k = 2 up-sampled-conv backward's own epilogue in bf16, snws_add_inplace for the others); the input gradient and every parameter gradient must equal what autograd's own accumulation
     gives (float32: to rounding of the summation order; bf16: one bf16 rounding per partial sum differs)."""
     from modeling.blocks import ConvSnRelu
     from snws import ops
@@ -212,7 +212,8 @@ def test_shared_gradient_slots_match_autograd_accumulation(dtype, tol):
     mods = [prod, c1, c2, ct]
     x = torch.randn(N, C, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
     g = [torch.randn(N, C, H, W, device=DEV), torch.randn(N, 2 * C, H, W, device=DEV), torch.randn(N, C, H // 2, W // 2, device=DEV),
-         torch.randn(N, C, 2 * H, 2 * W, device=DEV), torch.randn(N, C, 4 * H, 4 * W, device=DEV)]
+         torch.randn(N, C, 2 * H, 2 * W, device=DEV), torch.randn(N, C, 4 * H, 4 * W, device=DEV),
+         torch.randn(N, C, 8 * H, 8 * W, device=DEV)]
     res = {}
     saved = ops.GRAD_SHARE
     try:
@@ -225,12 +226,18 @@ def test_shared_gradient_slots_match_autograd_accumulation(dtype, tol):
             t = ops.share_grad(prod(xg))
             assert (ops.grad_slot(t) is not None) == share
             z = ops.share_grad(ct.taps(t))
-            outs = [c1(t), c2(t), ops.max_pool_ceil(t, 2), ct.up(z, 2), ct.up(z, 4)]
+            outs = [c1(t), c2(t), ops.max_pool_ceil(t, 2), ct.up(z, 2), ct.up(z, 4), ct.up(z, 8)]
             loss = sum((o.float() * gi).sum() for o, gi in zip(outs, g))
+            hits0 = ops.GRAD_SHARE_HITS
             loss.backward()
             tags = [r[0] for r in ops.PROFILE]
             ops.PROFILE = None
-            assert ("grad_add" in tags) == share          # the second consumer of the tap map adds with snws_add_inplace
+            # the tap map's consumers report in reverse order: k = 8 parks its gradient, k = 4 adds with snws_add_inplace,
+            # k = 2 adds in its own kernel (bf16) or with snws_add_inplace as well (float32)
+            assert ("grad_add" in tags) == share
+            if share:
+                assert tags.count("grad_add") == 1 if dtype == torch.bfloat16 else tags.count("grad_add") >= 2
+            assert (ops.GRAD_SHARE_HITS - hits0 >= 5) == share     # 3 later consumers of t, 2 of the tap map
             res[share] = [xg.grad.float().clone()] + [p.grad.float().clone() for m in mods for p in m.parameters()]
     finally:
         ops.GRAD_SHARE = saved
