@@ -1942,7 +1942,8 @@ class UpTapSnReluFn(torch.autograd.Function):
         slot, ctx.gslot = ctx.gslot, None
         dz, added = None, False
         parked = None if slot is None else slot.buf
-        if parked is not None and parked.dtype == dconv.dtype and tuple(parked.shape) == (N, CZ, h, w):
+        if parked is not None and k == 2 and parked.dtype == dconv.dtype == torch.bfloat16 and \
+                tuple(parked.shape) == (N, CZ, h, w):
             # a later consumer of a shared tap map: the kernel adds its share into the parked gradient where it can
             ps, ldp = as_nhwc(parked)
             if ps.data_ptr() == parked.data_ptr():
