@@ -65,6 +65,7 @@ out = ["## Round 3", "",
        "**%.1f images/s** (%.1f ms/step); kernel summary of a 4-step run: %s, libsnws %.1f %% of GPU time."
        % (bo["value"], bo["ms_per_step"], "no rocBLAS / hipBLASLt (`Cijk_*`) kernel" if not vendor else "VENDOR GEMM KERNELS PRESENT",
           100.0 * oours / otot),
+       '* `r03_bench_200steps_gpus1.json` - `bench.py --steps 200 --warmup 10`: 334.6 images/s sustained (47.81 ms/step) on another box of the pool; `r03_bench_disk_gpus1.json` - `bench.py --disk`: full-disk inference 38.1 ms per 2748x2748 disk (36 tiles, arg-max + stitch + Evaluator on the device; 946 tiles/s); `r03_bench_all_kernel_events.json` - `bench.py --all-kernel-events`: HIP-event time of every instrumented kernel family per step (the shared-gradient adds `grad_add` are 0.06 ms/step since the k = 2 up-sampled-conv backward adds in its own epilogue).',
        "* `r03_pmc_sq_conv_wgrad.txt` - SQ / GRBM counters of the 3x3 forward and weight-gradient kernels on the 320->320 layer "
        "(`tools/run_pmc.sh conv | wgrad`): the ping-pong weight-gradient kernel fetches 6.8 GB and writes 0.07 GB for 5.4 GB of operands (round 2: 18.1 + 1.2 GB), "
        "matrix pipe busy 78 % of the active cycles at an effective clock of 1.78 GHz; the forward kernel 76 % at 1.79 GHz.",
