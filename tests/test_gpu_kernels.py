@@ -2270,3 +2270,27 @@ def test_upconv_bwd_accumulating_form_equals_temporary_plus_add():
         L.call("snws_upconv_bwd_acc", P(dy4), Co, P(got), 9 * Co, L.SNWS_BF16, N, h, w, Co, 4, 3, st)
     torch.cuda.synchronize()
     assert torch.equal(got, keep)
+
+
+@pytest.mark.gpu
+def test_switchnorm_batch_falls_back_for_unaligned_channel_counts():
+    """Two SwitchNorm calls of 12 bf16 channels inside one stat_batch: the per-(image, channel) passes run batched, the
+    normalise pass cannot (24-byte pixels are not 16-byte lanes) and falls back to the single launches - same result as
+    without the batch."""
+    import modeling.snorm as sn
+    from snws import ops
+    N, C, H, W = 2, 12, 9, 14
+    torch.manual_seed(3)
+    mods = [sn.SwitchNorm2d(C).to(DEV).train() for _ in range(2)]
+    xs = [(torch.randn(N, C, H, W, device=DEV) * (i + 1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+          for i in range(2)]
+    want = [ops.sn_forward(x, ops.SNParams(m), True)[0].float().clone() for m, x in zip(mods, xs)]
+    for m in mods:
+        m.reset_parameters()
+        m.running_mean.zero_()
+        m.running_var.zero_()
+    with ops.stat_batch(None):
+        got = [ops.sn_forward(x, ops.SNParams(m), True)[0] for m, x in zip(mods, xs)]
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a.float(), b)
