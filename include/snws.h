@@ -326,6 +326,15 @@ int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, v
  * (modeling/UNet3p_res_ocr_SNws.py:130), and a further contribution to an input gradient with several contributors
  * (autograd's sum over the consumers of one tensor). */
 int snws_gemm1x1_acc(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int N, int K, void* stream);
+/* The same product (accumulate = 0: y = x w^T + bias; != 0: y += x w^T, no bias) whose store epilogue also hands a
+ * normalisation layer that follows - the nn.BatchNorm2d after every 1x1 nn.Conv2d of the OCR head,
+ * modeling/UNet3p_res_ocr_SNws.py:39-73,118-123 - the per-tile moments of the values it stored:
+ * stat_part[((img * T + t) * N + c) * 2 + {0, 1}] = sum and sum of squares of y over the 256 pixels of tile t of image
+ * img, T = snws_gemm1x1_stat_tiles(HW) (-1: HW is not a multiple of 256 - then use snws_sn_stats).  Feed it to
+ * snws_sn_finalize with an all-zero shift (shift_per_image = 0).  M = images * HW. */
+int snws_gemm1x1_stat_tiles(int64_t HW);
+int snws_gemm1x1_stats(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M, int N,
+                       int K, int accumulate, int64_t HW, float* stat_part, void* stream);
 
 /* The two attention steps of the OCR head as fused streaming kernels (bf16 NHWC pixel tensors, float32 soft-max, every
  * small product on the matrix cores; per-class results leave as per-wave partial rows to be summed with snws_partial_sum).

@@ -46,6 +46,12 @@ struct GemmArgs {
   int N, K, ntN;       // ntN: channel tiles per pixel tile
   unsigned ntiles;
   int accumulate;      // != 0: y += product (y holds a bf16 partial result or a gradient with several contributors)
+  // STATS instantiations (NR == 4, M and HW multiples of 256): per-tile per-channel sums of the STORED values (after
+  // rounding to bf16 and, when accumulating, after the add) for a normalisation layer that follows:
+  // stat[((img * Tn + tile) * N + c) * 2 + {0, 1}] = sum, sum of squares of y (no shift: a finalize pass takes shift 0)
+  float* stat;
+  int64_t HW;
+  int Tn;              // 256-pixel tiles per image
 };
 
 // WM x WN waves, each MR x NR MFMA tiles of 16 x 16: workgroup tile = (WM*MR*16 = 256 pixels) x (WN*NR*16 channels)
@@ -59,11 +65,13 @@ struct GemmGeom {
   static constexpr int NLOAD = AW + BW;                       // LDS-DMA loads per wave and step
   static constexpr int RS = NR * 32 + 16;                     // scratch bytes per pixel row (padded)
   static constexpr int SCR = 16 * RS;
-  static constexpr int LDS_BYTES = 2 * STAGE + 8 * SCR;
+  static constexpr int RED_BYTES = 8 * 64 * 2 * 4;            // per-wave channel partials of the statistics epilogue
+  static constexpr int LDS_BYTES = 2 * STAGE + 8 * SCR + RED_BYTES;
 };
 
-template <int WM, int WN, int MR, int NR>
+template <int WM, int WN, int MR, int NR, bool STATS = false>
 __global__ __launch_bounds__(512) void gemm1x1_kernel(GemmArgs a) {
+  static_assert(!STATS || NR == 4, "the statistics epilogue needs 8 chunks per row: a lane keeps its channel octet");
   using G = GemmGeom<WM, WN, MR, NR>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -139,6 +147,11 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(GemmArgs a) {
         b4[nr][j] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
       }
     constexpr int CPR = NR * 2, TOTAL = 16 * CPR, ITERS = (TOTAL + 63) / 64;   // 16-byte chunks per row / per slab
+    // statistics epilogue (CPR == 8: a lane keeps its channel octet lane & 7 through every store iteration)
+    constexpr bool stats = STATS;
+    float S[8], Q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) S[e] = Q[e] = 0.f;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
@@ -158,9 +171,62 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(GemmArgs a) {
           uint4 v = *reinterpret_cast<const uint4*>(scr + row * G::RS + c * 16);
           if (a.accumulate) v = add_bf16x8(v, *reinterpret_cast<const uint4*>(a.y + m * a.ldy + n));   // kernel-uniform
           *reinterpret_cast<uint4*>(a.y + m * a.ldy + n) = v;
+          if (stats) {
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float f0 = __uint_as_float(u[e] << 16);
+              const float f1 = __uint_as_float(u[e] & 0xffff0000u);
+              S[2 * e] += f0; Q[2 * e] = fmaf(f0, f0, Q[2 * e]);
+              S[2 * e + 1] += f1; Q[2 * e + 1] = fmaf(f1, f1, Q[2 * e + 1]);
+            }
+          }
         }
       }
       wave_lds_sync();
+    }
+    if (stats) {
+      // rows of a store iteration sit in lane bits 3..5: fold them, then the WM waves that share these channels (fixed
+      // order: bit-reproducible)
+      float* red = reinterpret_cast<float*>(smem + 2 * G::STAGE + 8 * G::SCR);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+          S[e] += __shfl_xor(S[e], o, 64);
+          Q[e] += __shfl_xor(Q[e], o, 64);
+        }
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[(wave * 64 + lane * 8 + e) * 2] = S[e];
+          red[(wave * 64 + lane * 8 + e) * 2 + 1] = Q[e];
+        }
+      }
+      // (raw barriers: __syncthreads would also wait for the tile's global stores)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (wm == 0) {
+        const int n = n0 + lane;
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) {
+          s_ += red[((w_ * WN + wn) * 64 + lane) * 2];
+          q_ += red[((w_ * WN + wn) * 64 + lane) * 2 + 1];
+        }
+        const int64_t mt = (int64_t)(t / a.ntN) * G::BM;        // first pixel of the tile: inside one image
+        const int64_t img = mt / a.HW, tile = (mt - img * a.HW) / G::BM;
+        if (n < a.N) {
+          float* o = a.stat + ((img * a.Tn + tile) * a.N + n) * 2;
+          o[0] = s_;
+          o[1] = q_;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // red is free again before any wave's next epilogue
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -207,13 +273,13 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(GemmArgs a) {
   }
 }
 
-template <int WM, int WN, int MR, int NR>
+template <int WM, int WN, int MR, int NR, bool STATS = false>
 int launch_gemm(GemmArgs a, hipStream_t st) {
   using G = GemmGeom<WM, WN, MR, NR>;
   static PerDeviceOnce once;
   std::atomic<bool>* const attr_set = once.flag();
   if (!attr_set || !attr_set->load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<WM, WN, MR, NR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<WM, WN, MR, NR, STATS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       snws_set_error("snws_gemm1x1: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -229,7 +295,7 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   }
   a.ntiles = (unsigned)tiles;
   const unsigned grid = a.ntiles < 256u ? a.ntiles : 256u;    // persistent: one workgroup per CU
-  gemm1x1_kernel<WM, WN, MR, NR><<<grid, 512, G::LDS_BYTES, st>>>(a);
+  gemm1x1_kernel<WM, WN, MR, NR, STATS><<<grid, 512, G::LDS_BYTES, st>>>(a);
   SNWS_LAUNCH_CHECK("snws_gemm1x1");
   return SNWS_OK;
 }
@@ -252,7 +318,7 @@ extern "C" int snws_gemm1x1_supported(int N, int K) { return N >= 64 && N % 8 ==
 
 namespace {
 int run_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M, int N, int K,
-                int accumulate, void* stream) {
+                int accumulate, void* stream, float* stat = nullptr, int64_t HW = 0) {
   SNWS_CHECK_ARG(x && w && y, "snws_gemm1x1: NULL pointer");
   if (!snws_gemm1x1_supported(N, K)) SNWS_UNSUPPORTED("snws_gemm1x1: N = %d (>= 64, multiple of 8), K = %d (multiple of 64)", N, K);
   SNWS_CHECK_ARG(M >= 1 && ldx >= K && ldx % 8 == 0 && ldy >= N && ldy % 8 == 0, "snws_gemm1x1: bad sizes");
@@ -262,6 +328,15 @@ int run_gemm1x1(const void* x, int64_t ldx, const void* w, const float* bias, vo
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y;
   a.ldx = ldx; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
+  if (stat) {
+    // the statistics epilogue exists for the 256- and 128-wide channel tiles: the one with less padded work
+    const int bn = cdiv(N, 256) * 256 <= cdiv(N, 128) * 128 ? 256 : 128;
+    if (HW < 256 || HW % 256 || M % HW)
+      SNWS_UNSUPPORTED("snws_gemm1x1_stats: needs whole 256-pixel tiles per image (HW = %lld, M = %lld)", (long long)HW,
+                       (long long)M);
+    a.stat = stat; a.HW = HW; a.Tn = (int)(HW / 256);
+    return bn == 256 ? launch_gemm<2, 4, 8, 4, true>(a, st) : launch_gemm<4, 2, 4, 4, true>(a, st);
+  }
   switch (pick_bn(N)) {
     case 256: return launch_gemm<2, 4, 8, 4>(a, st);
     case 192: return launch_gemm<2, 4, 8, 3>(a, st);
@@ -279,4 +354,13 @@ extern "C" int snws_gemm1x1(const void* x, int64_t ldx, const void* w, const flo
 extern "C" int snws_gemm1x1_acc(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int N, int K,
                                 void* stream) {
   return run_gemm1x1(x, ldx, w, nullptr, y, ldy, M, N, K, 1, stream);
+}
+
+extern "C" int snws_gemm1x1_stat_tiles(int64_t HW) { return (HW >= 256 && HW % 256 == 0) ? (int)(HW / 256) : -1; }
+
+extern "C" int snws_gemm1x1_stats(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t M,
+                                  int N, int K, int accumulate, int64_t HW, float* stat_part, void* stream) {
+  SNWS_CHECK_ARG(stat_part, "snws_gemm1x1_stats: NULL stat_part");
+  SNWS_CHECK_ARG(!(accumulate && bias), "snws_gemm1x1_stats: no bias in accumulate mode");
+  return run_gemm1x1(x, ldx, w, bias, y, ldy, M, N, K, accumulate, stream, stat_part, HW);
 }

@@ -19,6 +19,7 @@ from torch.nn.modules.utils import _pair
 import modeling.snorm as sn
 import modeling.weightstd as ws
 from modeling.blocks import (ConvSnRelu, FusedAway, HipBatchNorm2d, PlainConv2d, PoolPyramid, Resnet_BasicBlock,  # noqa: F401
+                             link_conv_bn,
                              crop_concat as CropConcat,
                              full_scale_decoder, head_conv, plain_conv, to_device_layout)
 from snws import ops
@@ -112,7 +113,9 @@ class SpatialOCR_Module(nn.Module):
         conv, bn, _, drop = self.conv_bn_dropout
         if ops.conv1x1_pair_ok(context, feats, conv):
             # conv(cat([context, feats])) = W[:, :C] context + W[:, C:] feats: the concatenation is never built
-            return bn.with_dropout(ops.Conv1x1PairFn.apply(context, feats, conv.weight), drop)
+            want_stats = conv.emit_stats and conv.training
+            y = ops.Conv1x1PairFn.apply(context, feats, conv.weight, want_stats)
+            return bn.with_dropout(ops.attach_stat(y) if want_stats else y, drop)
         return bn.with_dropout(conv(torch.cat([context, feats], 1)), drop)
 
 
@@ -177,6 +180,7 @@ class UNet3p_res_ocr_SNws(nn.Module):
         self.output_seg_map = nn.Conv2d(f, n_class, kernel_size=1, stride=1, padding=0)   # registered, unused (:294)
         self.compute_dtype = None      # None: keep the input's dtype; torch.bfloat16 for the MFMA tier
         self.raw_logits = False        # True: return the head kernel's own (padded, compute-dtype) output
+        link_conv_bn(self)             # conv -> BatchNorm pairs: the conv's epilogue sums the moments
 
     def forward(self, x):
         x = to_device_layout(x, self.compute_dtype)

@@ -113,7 +113,10 @@ def plain_conv(conv, x, raw=False):
     if pad:
         w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, pad))
         b = None if b is None else torch.nn.functional.pad(b, (0, pad))
-    y = ops.PlainConvFn.apply(x, w, b)
+    want_stats = bool(getattr(conv, "emit_stats", False)) and conv.training and not pad
+    y = ops.PlainConvFn.apply(x, w, b, want_stats)
+    if want_stats:
+        ops.attach_stat(y)
     return y if (raw or not pad) else y[:, :n_out]
 
 
@@ -132,7 +135,10 @@ def finish_logits(raw16, n_class, raw=False):
 
 
 class PlainConv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters, same state_dict keys) whose forward runs the library's conv kernels."""
+    """nn.Conv2d (same parameters, same state_dict keys) whose forward runs the library's conv kernels.  emit_stats
+    (set by link_conv_bn for a convolution whose only reader is a HipBatchNorm2d): the kernel's epilogue also sums the
+    output's per-tile moments, so the normalisation does not re-read the tensor for them."""
+    emit_stats = False
 
     def forward(self, x):
         return plain_conv(self, x)
@@ -173,6 +179,18 @@ class HipBatchNorm2d(nn.BatchNorm2d):
             return drop(self(x))
         noise = x.new_empty((x.shape[0], x.shape[1], 1, 1)).bernoulli_(1.0 - drop.p).div_(1.0 - drop.p)
         return self(x, post=noise)
+
+
+def link_conv_bn(root):
+    """Marks every PlainConv2d that an nn.Sequential feeds straight into a HipBatchNorm2d (conv -> BN -> ReLU triples
+    of the OCR head, modeling/UNet3p_res_ocr_SNws.py:39-73,118-123,269-274) so that it emits the moments the
+    normalisation needs."""
+    for m in root.modules():
+        if isinstance(m, nn.Sequential):
+            for a, b in zip(list(m)[:-1], list(m)[1:]):
+                if isinstance(a, PlainConv2d) and isinstance(b, HipBatchNorm2d):
+                    a.emit_stats = True
+    return root
 
 
 class FusedAway(nn.Identity):

@@ -96,6 +96,8 @@ _SIGNATURES = {
     "snws_gemm1x1_supported": (c_int, [c_int, c_int]),
     "snws_gemm1x1": (c_int, [P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int, P]),
     "snws_gemm1x1_acc": (c_int, [P, c_int64, P, P, c_int64, c_int64, c_int, c_int, P]),
+    "snws_gemm1x1_stat_tiles": (c_int, [c_int64]),
+    "snws_gemm1x1_stats": (c_int, [P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int64, P, P]),
     "snws_ocr_tiles": (c_int, [c_int64, c_int]),
     "snws_ocr_gather_stats": (c_int, [P, c_int64, P, c_int, c_int64, c_int, c_float, P]),
     "snws_ocr_gather_fwd": (c_int, [P, c_int64, P, c_int64, P, P, c_int, c_int64, c_int, c_int, c_float, P]),
@@ -159,7 +161,7 @@ _SIGNATURES = {
 # entry points that return a status code (the others return a value)
 _STATUS = {k for k, (res, _) in _SIGNATURES.items() if res is c_int} - {
     "snws_version", "snws_conv_out_size", "snws_conv_mfma_tiles", "snws_sn_stats_tiles", "snws_ce_blocks",
-    "snws_upconv_stat_tiles", "snws_upconv_fwd_mode", "snws_upconv_bwd_mode", "snws_tile_minmax_blocks", "snws_conv_f32_tiles", "snws_sn_head_tiles", "snws_gemm1x1_supported", "snws_ocr_tiles", "snws_ocr32_runs"}
+    "snws_upconv_stat_tiles", "snws_upconv_fwd_mode", "snws_upconv_bwd_mode", "snws_tile_minmax_blocks", "snws_conv_f32_tiles", "snws_sn_head_tiles", "snws_gemm1x1_supported", "snws_gemm1x1_stat_tiles", "snws_ocr_tiles", "snws_ocr32_runs"}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1148,12 +1148,21 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
     world = sync_world(group) if synced else 1
     pack = None
     if use_batch:
-        T = lib.snws_sn_stats_tiles(N, HW, C)
-        part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
-        shift = torch.empty((N, C), dtype=torch.float32, device=dev)
-        _launch("sn_stats", float(x.element_size()) * N * HW * C, "snws_sn_stats", _ptr(xs), dt, N, HW, C, ldx,
-                _ptr(part), _ptr(shift), st)
-        L.call("snws_sn_finalize", _ptr(part), T, _ptr(shift), 1, N, HW, C, _ptr(ctx), st)
+        fused = getattr(x, "_snws_stat", None)
+        if fused is not None and (fused["ptr"] != xs.data_ptr() or fused["version"] != x._version or
+                                  fused["shape"] != (N, C, H, W) or tuple(fused["part"].shape) != (N, fused["T"], C, 2)):
+            fused = None
+        if fused is not None:       # the producing convolution's epilogue already summed the moments
+            global BN_STAT_HITS
+            BN_STAT_HITS += 1
+            L.call("snws_sn_finalize", _ptr(fused["part"]), fused["T"], _ptr(fused["shift"]), 0, N, HW, C, _ptr(ctx), st)
+        else:
+            T = lib.snws_sn_stats_tiles(N, HW, C)
+            part = torch.empty((N, T, C, 2), dtype=torch.float32, device=dev)
+            shift = torch.empty((N, C), dtype=torch.float32, device=dev)
+            _launch("sn_stats", float(x.element_size()) * N * HW * C, "snws_sn_stats", _ptr(xs), dt, N, HW, C, ldx,
+                    _ptr(part), _ptr(shift), st)
+            L.call("snws_sn_finalize", _ptr(part), T, _ptr(shift), 1, N, HW, C, _ptr(ctx), st)
         pack = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
         L.call("snws_bn_pack", _ptr(ctx), N, HW, C, _ptr(pack), st)
         if synced:
@@ -1266,7 +1275,25 @@ def gemm1x1_ok(n_out, n_in):
     return GEMM_1X1 and bool(L.lib().snws_gemm1x1_supported(int(n_out), int(n_in)))
 
 
-def gemm1x1(x, w2d, bias=None, tag="gemm1x1_fwd", out=None, accumulate=False):
+# Per-tile moments a convolution's store epilogue left for the normalisation layer behind it (conv -> BatchNorm pairs of
+# the OCR head): the producer attaches them to its output tensor, bn_forward uses them if the tensor it receives is
+# that very tensor, unmodified, and otherwise runs its own statistics pass.
+BN_STAT_FUSION = os.environ.get("SNWS_BN_STAT_FUSION", "1") != "0"
+BN_STAT_HITS = 0        # BatchNorm calls that took their moments from the producer (tests read it)
+_LAST_STAT = None
+
+
+def attach_stat(y):
+    """Moves the moments the last producer left (see _LAST_STAT) onto its output tensor y."""
+    global _LAST_STAT
+    st, _LAST_STAT = _LAST_STAT, None
+    if st is not None and st["ptr"] == y.data_ptr() and st["shape"] == tuple(y.shape):
+        st["version"] = y._version
+        y._snws_stat = st
+    return y
+
+
+def gemm1x1(x, w2d, bias=None, tag="gemm1x1_fwd", out=None, accumulate=False, want_stats=False):
     """y[n, :, h, w] = w2d @ x[n, :, h, w] (+ bias) for a logical (N, K, H, W) bf16 tensor x with channels-last storage
     (a channel slice of a wider buffer is fine) and a bf16 (C_out, K) matrix; returns (y, x's NHWC view, its pixel
     stride).  out: an existing (N, C_out, H, W) NHWC bf16 tensor to write; with accumulate the product is added to it."""
@@ -1279,9 +1306,18 @@ def gemm1x1(x, w2d, bias=None, tag="gemm1x1_fwd", out=None, accumulate=False):
     ys, ldy = as_nhwc(y)
     if ys.data_ptr() != y.data_ptr() or y.dtype != torch.bfloat16 or tuple(y.shape) != (N, n_out, H, W):
         raise RuntimeError("gemm1x1: out must be an NHWC bf16 tensor of the result's shape")
-    if accumulate:
-        if bias is not None:
-            raise RuntimeError("gemm1x1: no bias in accumulate mode")
+    if accumulate and bias is not None:
+        raise RuntimeError("gemm1x1: no bias in accumulate mode")
+    T = L.lib().snws_gemm1x1_stat_tiles(H * W) if (want_stats and BN_STAT_FUSION) else -1
+    if T > 0:
+        global _LAST_STAT
+        b32 = None if bias is None else (bias.detach() if bias.dtype == torch.float32 else bias.detach().float())
+        stat = torch.empty((N, T, n_out, 2), dtype=torch.float32, device=x.device)
+        _launch(tag, 2.0 * N * H * W * n_out * K, "snws_gemm1x1_stats", _ptr(xs), ldx, _ptr(w2d), _ptr(b32), _ptr(ys), ldy,
+                N * H * W, n_out, K, int(bool(accumulate)), H * W, _ptr(stat), _stream())
+        _LAST_STAT = dict(ptr=y.data_ptr(), shape=tuple(y.shape), part=stat, T=T,
+                          shift=torch.zeros(n_out, dtype=torch.float32, device=x.device))
+    elif accumulate:
         _launch(tag, 2.0 * N * H * W * n_out * K, "snws_gemm1x1_acc", _ptr(xs), ldx, _ptr(w2d), _ptr(ys), ldy, N * H * W, n_out,
                 K, _stream())
     else:
@@ -1336,7 +1372,10 @@ class PlainConvFn(torch.autograd.Function):
     """A plain (not standardized) convolution through the same kernels - the nn.Conv2d classification head."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
+        # want_stats: a normalisation layer reads the output next - leave it the output's per-tile moments (attach_stat)
+        global _LAST_STAT
+        _LAST_STAT = None
         cfg = ConvCfg(weight.shape, 1, (weight.shape[2] - 1) // 2, 1, 1)
         ctx.in_segs, ctx.gslot = input_segments(x), grad_slot(x)
         ctx.gemm_w = None
@@ -1346,14 +1385,17 @@ class PlainConvFn(torch.autograd.Function):
             # stays on snws_conv_mfma_wgrad (f32 result)
             N, C, H, W = x.shape
             wb = weight.detach().reshape(cfg.O, C).to(torch.bfloat16)
-            y, xs, ldx = gemm1x1(x, wb, bias)
+            y, xs, ldx = gemm1x1(x, wb, bias, want_stats=want_stats)
             ctx.gemm_w = wb
             ctx.prep = _PlainCfg(cfg)
             ctx.saved, ctx.has_bias, ctx.bias_key = (xs, ldx, (N, C, H, W), True), bias is not None, grad_key(bias)
             ctx.save_for_backward(weight)
             return y
         prep = PreparedWeight(weight, cfg, x.dtype == torch.bfloat16, standardize=False)
-        y, _, saved = conv_forward(x, prep, bias)
+        y, stat, saved = conv_forward(x, prep, bias, want_stats=bool(want_stats and BN_STAT_FUSION))
+        if stat is not None:      # (N, T, C, 2) moments of (y - bias) from the conv epilogue
+            shift = _f32c(bias).view(-1) if bias is not None else torch.zeros(cfg.O, dtype=torch.float32, device=x.device)
+            _LAST_STAT = dict(ptr=y.data_ptr(), shape=tuple(y.shape), part=stat, T=stat.shape[1], shift=shift)
         ctx.prep, ctx.saved, ctx.has_bias, ctx.bias_key = prep, saved, bias is not None, grad_key(bias)
         ctx.save_for_backward(weight)
         return y
@@ -1375,12 +1417,12 @@ class PlainConvFn(torch.autograd.Function):
                     lddy = dys.shape[1]
                 dw, db = _conv_backward_weights(dys, lddy, ctx.prep, ctx.saved, weight, nw, nb, ctx.bias_key)
             ctx.saved = ctx.gemm_w = ctx.gslot = None
-            return dx, None if dw is None else dw.to(weight.dtype), db
+            return dx, None if dw is None else dw.to(weight.dtype), db, None
         dx, dw, db = conv_backward(dy, ctx.prep, ctx.saved, weight, nx, nw, nb, ctx.bias_key, ctx.in_segs, ctx.gslot)
         ctx.in_segs = ctx.gslot = None
         if dw is not None:
             dw = dw.to(weight.dtype)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 PAIR_CONV = os.environ.get("SNWS_PAIR_CONV", "1") != "0"            # A/B switch of Conv1x1PairFn
@@ -1404,13 +1446,15 @@ class Conv1x1PairFn(torch.autograd.Function):
     slot when it has one)."""
 
     @staticmethod
-    def forward(ctx, a, b, weight):
+    def forward(ctx, a, b, weight, want_stats=False):
+        global _LAST_STAT
+        _LAST_STAT = None
         N, Ca, H, W = a.shape
         Cb, O = b.shape[1], weight.shape[0]
         w2 = weight.detach().reshape(O, Ca + Cb).to(torch.bfloat16)
         wa, wb = w2[:, :Ca].contiguous(), w2[:, Ca:].contiguous()
         y, as_, lda = gemm1x1(a, wa, None, tag="gemm1x1_fwd")
-        _, bs, ldb = gemm1x1(b, wb, None, tag="gemm1x1_fwd", out=y, accumulate=True)
+        _, bs, ldb = gemm1x1(b, wb, None, tag="gemm1x1_fwd", out=y, accumulate=True, want_stats=want_stats)
         ctx.saved = (as_, lda, bs, ldb, wa, wb, (N, Ca, Cb, O, H, W))
         ctx.slots = (grad_slot(a), grad_slot(b))
         ctx.save_for_backward(weight)
@@ -1439,7 +1483,7 @@ class Conv1x1PairFn(torch.autograd.Function):
                 halves.append(g)
             dw = torch.cat(halves, 1).to(weight.dtype)
         ctx.saved = ctx.slots = None
-        return da, db, dw
+        return da, db, dw, None
 
 
 class SwitchNormFn(torch.autograd.Function):

@@ -557,9 +557,13 @@ def test_res_ocr_full_size_one_pass_forms_match_the_composed_ones():
     model.compute_dtype = torch.bfloat16
     img, _ = harness.synthetic_batch(16, 14, 512, 10, torch.device(DEV))
     lab = img[:, :10].argmax(1)
-    saved = (ops.GRAD_SHARE, ops.PAIR_CONV, ops.DROPOUT_FOLD)
+    saved = (ops.GRAD_SHARE, ops.PAIR_CONV, ops.DROPOUT_FOLD, ops.BN_STAT_FUSION)
     res = {}
     try:
+        # (both runs take the BatchNorm moments from a statistics pass over the tensor: where the moments come from is
+        # not what this test compares, and in bf16 a 1e-7 change of a layer's statistics already moves this model's
+        # gradients by 1 % - see tests/test_gpu_ocr.py for the fused moments)
+        ops.BN_STAT_FUSION = False
         for on in (True, False):
             ops.GRAD_SHARE = ops.PAIR_CONV = ops.DROPOUT_FOLD = on
             model.zero_grad(set_to_none=True)
@@ -569,7 +573,7 @@ def test_res_ocr_full_size_one_pass_forms_match_the_composed_ones():
             res[on] = (loss.item(), [p.grad.float().clone() for p in model.parameters() if p.grad is not None])
             del loss
     finally:
-        ops.GRAD_SHARE, ops.PAIR_CONV, ops.DROPOUT_FOLD = saved
+        ops.GRAD_SHARE, ops.PAIR_CONV, ops.DROPOUT_FOLD, ops.BN_STAT_FUSION = saved
     assert abs(res[True][0] - res[False][0]) < 1e-3 * abs(res[False][0]), (res[True][0], res[False][0])
     def l2(a, b):
         return float((a - b).norm() / max(float(b.norm()), 1e-30))

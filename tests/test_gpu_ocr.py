@@ -295,3 +295,87 @@ def test_ocr_modules_raise_on_unsupported_input():
     probs = torch.randn(1, 3, 4, 4, device=DEV, dtype=torch.float64)
     with pytest.raises(RuntimeError, match="HIP kernels only"):
         SpatialGather_Module(3)(feats, probs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,acc,bias", [(256, 512, False, True), (512, 256, False, False), (320, 320, False, True),
+                                           (512, 512, True, False), (64, 128, False, True)])
+def test_gemm1x1_statistics_epilogue(N, K, acc, bias):
+    """snws_gemm1x1_stats: the product must equal snws_gemm1x1 / snws_gemm1x1_acc bit for bit, and the per-tile moments
+    must be the sums of the STORED bf16 values over each 256-pixel tile (float64 reference from the stored tensor), for
+    both channel-tile widths (256, 128 incl. a ragged last tile at 320), with a bias and in accumulate mode."""
+    import ctypes
+    from snws import _lib as L
+    torch.manual_seed(N + K)
+    imgs, HW = 3, 512
+    M = imgs * HW
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV) if bias else None
+    base = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    want = base.clone()
+    if acc:
+        L.call("snws_gemm1x1_acc", P(x), K, P(w), P(want), N, M, N, K, st)
+    else:
+        L.call("snws_gemm1x1", P(x), K, P(w), P(b), P(want), N, M, N, K, st)
+    T = L.lib().snws_gemm1x1_stat_tiles(HW)
+    assert T == 2 and L.lib().snws_gemm1x1_stat_tiles(300) == -1
+    got = base.clone()
+    stat = torch.full((imgs, T, N, 2), float("nan"), device=DEV)
+    L.call("snws_gemm1x1_stats", P(x), K, P(w), P(b), P(got), N, M, N, K, int(acc), HW, P(stat), st)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    y = got.double().view(imgs, T, 256, N)
+    ref = torch.stack([y.sum(2), (y * y).sum(2)], -1)
+    assert bool(torch.isfinite(stat).all())
+    err = (stat.double() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2e-6, float(err)
+    with pytest.raises(L.SnwsUnsupported):
+        L.call("snws_gemm1x1_stats", P(x), K, P(w), P(b), P(got), N, M, N, K, int(acc), 300, P(stat), st)
+
+
+@pytest.mark.gpu
+def test_ocr_head_batchnorm_takes_moments_from_the_convolutions():
+    """UNet3p_res_ocr_SNws in bf16: the BatchNorm layers behind the wide 1x1 convolutions, the 3x3 convolution and the
+    two-product 1x1 convolution take their moments from the producing kernel's epilogue (ops.BN_STAT_HITS counts them);
+    logits, running statistics and gradients agree with the run that re-reads every tensor for its statistics
+    (SNWS_BN_STAT_FUSION=0 path) to bf16 rounding of the running buffers' inputs."""
+    from modeling.UNet3p_res_ocr_SNws import UNet3p_res_ocr_SNws
+    from snws import ops
+
+    def run(fuse):
+        torch.manual_seed(8)
+        model = UNet3p_res_ocr_SNws(14, 16, 10, 1, 1).to(DEV).train()
+        model.compute_dtype = torch.bfloat16
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        g = torch.Generator().manual_seed(4)
+        img = (torch.rand(2, 14, 64, 64, generator=g) * 255.0).to(DEV)
+        lab = torch.randint(0, 10, (2, 64, 64), generator=g).to(DEV)
+        old, ops.BN_STAT_FUSION = ops.BN_STAT_FUSION, fuse
+        hits0 = ops.BN_STAT_HITS
+        try:
+            out = model(img)
+            logits = out[1] if isinstance(out, (tuple, list)) else out
+            aux = out[0] if isinstance(out, (tuple, list)) else None
+            loss = torch.nn.functional.cross_entropy(logits.float(), lab)
+            if aux is not None:
+                loss = loss + 0.4 * torch.nn.functional.cross_entropy(aux.float(), lab)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.BN_STAT_FUSION = old
+        bufs = {k: v.detach().float().cpu().clone() for k, v in model.named_buffers() if "running" in k}
+        grads = torch.cat([p.grad.detach().float().flatten().cpu() for p in model.parameters() if p.grad is not None])
+        return logits.detach().float().cpu(), bufs, grads, ops.BN_STAT_HITS - hits0
+
+    l1, b1, g1, hits = run(True)
+    l0, b0, g0, hits0 = run(False)
+    assert hits0 == 0 and hits >= 6, (hits, hits0)
+    assert l2err(l1, l0) < 2e-2
+    for k in b1:
+        assert float((b1[k] - b0[k]).abs().max()) <= 2e-3 * float(b0[k].abs().max()) + 1e-5, k
+    assert torch.isfinite(g1).all()
